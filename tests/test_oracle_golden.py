@@ -1,0 +1,107 @@
+"""The oracle (oracle/plspy_oracle.py) against golden vectors generated from the
+reference's own plspy.core (tests/golden/make_golden.py).  This is what pins the
+oracle; the GPU parity tests then compare the HIP path with the oracle."""
+import numpy as np
+import pytest
+
+from tests._util import assert_close, golden_names, load_golden, nonnull, run_oracle_case
+
+RT = 1e-10   # relative tolerance for float results (same machine, same BLAS)
+
+
+@pytest.fixture(scope="module", params=golden_names())
+def case(request):
+    fx = load_golden(request.param)
+    np.random.seed(fx["seed"])
+    raw = []
+    perm0, choice0 = np.random.permutation, np.random.choice
+
+    def perm(x):
+        out = perm0(x)
+        raw.append(np.asarray(out).copy())
+        return out
+
+    def choice(*a, **k):
+        out = choice0(*a, **k)
+        raw.append(np.asarray(out).copy())
+        return out
+
+    np.random.permutation, np.random.choice = perm, choice
+    try:
+        out = run_oracle_case(fx)
+    finally:
+        np.random.permutation, np.random.choice = perm0, choice0
+    out["raw_draws"] = raw
+    return fx, out
+
+
+def test_draws_identical(case):
+    """Same np.random legacy calls, same order, same values as the reference."""
+    fx, out = case
+    assert len(out["raw_draws"]) == len(fx["draws"])
+    for mine, ref in zip(out["raw_draws"], fx["draws"]):
+        np.testing.assert_array_equal(mine, ref)
+
+
+def test_observed(case):
+    fx, out = case
+    obs = out["obs"]
+    if fx["method"] == "mct":
+        assert_close(obs["X_mc"], fx["X_mc"], RT, 1e-13, "X_mc")
+        assert_close(obs["X_means"], fx["X_means"], RT, 1e-13, "X_means")
+    if fx["method"] == "rb":
+        assert_close(obs["R"], fx["R"], RT, 1e-13, "R")
+    if fx["method"] == "mb":
+        assert_close(obs["multiblock"], fx["multiblock"], RT, 1e-13, "multiblock")
+
+
+def test_permutation(case):
+    fx, out = case
+    if not fx["nperm"]:
+        pytest.skip("no permutations")
+    perm = out["perm"]
+    if "s_list" in fx:
+        assert_close(perm["s_list"], fx["s_list"], RT, 1e-11, "s_list")
+    # integer counts: exact
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(perm["permute_ratio"] * n1), np.rint(fx["permute_ratio"] * n1))
+    np.testing.assert_array_equal(np.rint(perm["stepdown_ratio"] * n1), np.rint(fx["stepdown_ratio"] * n1))
+
+
+def test_bootstrap(case):
+    fx, out = case
+    if not fx["nboot"]:
+        pytest.skip("no bootstraps")
+    boot = out["boot"]
+    assert_close(boot["right_sv_sampled"], fx["right_sv_sampled"], RT, 1e-12, "right_sv_sampled")
+    assert_close(boot["left_sv_sampled"], fx["left_sv_sampled"], 1e-9, 1e-12, "left_sv_sampled")
+    live = nonnull(fx)
+    assert_close(boot["std_errs"][:, live], fx["std_errs"][:, live], 1e-9, 1e-13, "std_errs")
+    assert_close(boot["boot_ratios"][:, live], fx["boot_ratios"][:, live], 1e-8, 1e-10, "boot_ratios")
+    assert_close(boot["conf_ints"][0][:, live], fx["conf_lo"][:, live], 1e-9, 1e-12, "conf lo")
+    assert_close(boot["conf_ints"][1][:, live], fx["conf_hi"][:, live], 1e-9, 1e-12, "conf hi")
+    if "LVcorr" in fx:
+        assert_close(boot["LVcorr"][:, :, live], fx["LVcorr"][:, :, live], 1e-9, 1e-12, "LVcorr")
+    if "confT_lo" in fx:
+        assert_close(boot["conf_ints_T"][0][:, live], fx["confT_lo"][:, live], 1e-9, 1e-12, "confT lo")
+        assert_close(boot["conf_ints_T"][1][:, live], fx["confT_hi"][:, live], 1e-9, 1e-12, "confT hi")
+
+
+def test_split_half(case):
+    fx, out = case
+    if not fx["num_split"]:
+        pytest.skip("no split-half")
+    for tag in ("tt", "sh"):
+        res = out[tag]
+        for key, val in res.items():
+            ref = fx[f"{tag}_{key}"]
+            val = np.asarray(val)
+            if val.ndim == 3:
+                # d x d x S slabs: sign of each singular-vector pair is
+                # LAPACK's; same LAPACK here, so compare directly.  Null
+                # latent variables (arbitrary basis) are excluded via nan/inf
+                # tolerant comparison on the leading `lv` block only.
+                lv = fx["lv"]
+                assert_close(val[:lv, :lv], ref[:lv, :lv], 1e-7, 1e-9, f"{tag}:{key}")
+            else:
+                assert_close(val[: fx["lv"]], ref[: fx["lv"]], 1e-6, 1e-9, f"{tag}:{key}")
