@@ -1,0 +1,131 @@
+/*
+ * plsr.h -- C ABI of the MI355X (gfx950) PLS resampling engine.
+ *
+ * plspy itself has no FFI: its hot path is NumPy called from three Python
+ * seams.  Each entry point below names the reference
+ * arithmetic it replaces (file:line under plspy/core of McIntosh-Lab/plspy).
+ * A maintainer of the reference binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (hipMalloc / torch tensor
+ *     .data_ptr()); the caller owns every buffer, the library allocates nothing.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All
+ *     entry points only enqueue work; none synchronises.
+ *   - return value: 0 = ok, <0 = error (plsr_strerror).  No C++ exception
+ *     crosses the boundary.
+ *   - fp64 everywhere, int32 indices, row-major, voxel = unit stride.
+ */
+#ifndef PLSR_H
+#define PLSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLSR_OK 0
+#define PLSR_EINVAL (-1)      /* bad argument / shape                          */
+#define PLSR_EUNSUPPORTED (-2)/* shape outside what the kernels are built for  */
+#define PLSR_EWORKSPACE (-3)  /* workspace too small                           */
+#define PLSR_ELAUNCH (-4)     /* hip launch error (see plsr_last_hip_error)    */
+
+#define PLSR_VOXEL_TILE 64    /* voxels owned by one workgroup                 */
+
+int plsr_abi_version(void);
+const char *plsr_strerror(int code);
+int plsr_last_hip_error(void);
+
+/*
+ * Layout of a batch of R resamples x k latent variables as MFMA operand
+ * fragments.  Column (b, j) of the batch is the n-vector `op` such that the
+ * resample's projected cross-block is  VS_b[v, j] = sum_i X[i, v] * op[i].
+ * Columns are grouped in "quads" (one latent variable, four consecutive
+ * resamples) and four quads make one 16-row MFMA tile, so that the four
+ * accumulator registers of a lane are four resamples of ONE latent variable
+ * and the sum over resamples needs no cross-lane traffic.
+ */
+typedef struct plsr_layout {
+  int32_t n;        /* rows of X                                             */
+  int32_t k;        /* latent variables per resample                         */
+  int32_t R;        /* resamples in the batch                                */
+  int32_t nk;       /* k-steps: ceil(n / 4)                                  */
+  int32_t kp;       /* k padded so that the tile pattern has a short period  */
+  int32_t period;   /* tiles after which the (slot, lane-group) -> lv map repeats */
+  int32_t Rp;       /* R rounded up to a multiple of 4                       */
+  int32_t ntiles;   /* 16-column tiles in the batch                          */
+  int64_t frag_elems; /* doubles in the fragment buffer: ntiles * nk * 64    */
+} plsr_layout_t;
+
+/* Fills *out.  PLSR_EUNSUPPORTED when k needs a period the kernels lack. */
+int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *out);
+
+/*
+ * Operator columns from row-selection indices.
+ *   op_(b,j)[i] = sum over r with inds[b][r] == i of M[r][j]      (r ascending)
+ * With M = W^T U (W = the mean-centring operator, U = observed left singular
+ * vectors) this is the fold of
+ *     X[inds,:]                      resample.py:79, :153
+ *     _mean_centre(...)              class_functions.py:7-95
+ *     permuted.T @ U                 bootstrap_permutation.py:404, :620
+ * into one (n x k) operator per resample, so X is never gathered.
+ *   d_inds : [R][n] int32      d_M : [n][k] fp64      d_frag : frag_elems fp64
+ */
+int plsr_ops_from_indices(const int32_t *d_inds, const double *d_M,
+                          const plsr_layout_t *lay, double *d_frag, void *stream);
+
+/*
+ * Operator columns given densely: d_cols[b][j][i] (R x k x n fp64), for
+ * preprocessors whose operator is not a row selection (behaviour PLS).
+ */
+int plsr_ops_pack(const double *d_cols, const plsr_layout_t *lay, double *d_frag,
+                  void *stream);
+
+/* Bytes of scratch the two batch calls below need for p voxels. */
+size_t plsr_batch_workspace_bytes(const plsr_layout_t *lay, int64_t p, int32_t k2);
+
+/*
+ * Permutation batch.  For every resample b and latent variable j:
+ *     d_ssq[b][j] = sum_v ( sum_i X[i,v] * op_(b,j)[i] )^2
+ * i.e. s_hat^2 of bootstrap_permutation.py:404-405.
+ *   d_X : [n][ldx] fp64 (ldx >= p)        d_ssq : [R][k] fp64 (overwritten)
+ */
+int plsr_perm_batch(const double *d_X, int64_t ldx, int64_t p,
+                    const double *d_frag, const plsr_layout_t *lay,
+                    double *d_ssq, void *d_work, size_t work_bytes, void *stream);
+
+/*
+ * Bootstrap batch.  With VS_b = X^T op_b (p x k), streams instead of storing
+ * right_sv_sampled (bootstrap_permutation.py:497, :626, :695):
+ *     d_S1[v][j] += sum_b (VS_b[v,j] - ref[v][j])
+ *     d_S2[v][j] += sum_b (VS_b[v,j] - ref[v][j])^2         (shifted moments)
+ *     d_ssq[b][j] = sum_v VS_b[v,j]^2                        (:623 norms)
+ *     d_T[b][j][c] = sum_v Xm[c][v] * VS_b[v,j]              (:633-634 before
+ *                    the column normalisation, with Xm = the k2 x p cell means
+ *                    of X: group_condition_means(X @ V_hat) = (Wm X) V_hat)
+ *   d_ref : [p][k] or NULL (= 0)      d_Xm : [k2][ldxm], k2 <= 16, or NULL
+ *   d_vs_dump : [R][p][k] or NULL     (materialised VS, for tests / debug)
+ * d_S1/d_S2 are accumulated into (caller zeroes them before the first batch).
+ */
+int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p,
+                    const double *d_frag, const plsr_layout_t *lay,
+                    const double *d_ref, const double *d_Xm, int64_t ldxm, int32_t k2,
+                    double *d_S1, double *d_S2, double *d_ssq, double *d_T,
+                    double *d_vs_dump,
+                    void *d_work, size_t work_bytes, void *stream);
+
+/*
+ * Bootstrap summary from the streamed moments (bootstrap_permutation.py:695-703):
+ *     std[e]   = sqrt( max( S2[e]/R - (S1[e]/R)^2 , 0 ) )      np.std, ddof = 0
+ *     ratio[e] = num[e] / std[e]                               boot_ratios
+ * for e in [0, count); S1/S2 are the shifted sums of plsr_boot_batch summed over
+ * all batches (and all GPUs).  d_num = V*s (or V with contrasts).
+ */
+int plsr_boot_finalize(const double *d_S1, const double *d_S2, const double *d_num,
+                       int64_t count, int32_t R, double *d_std, double *d_ratio, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSR_H */

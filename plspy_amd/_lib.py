@@ -1,0 +1,71 @@
+"""ctypes binding of include/plsr.h.
+
+The library is loaded from the source tree (plspy_amd/csrc/libplsr_hip.so).
+torch is imported first so that the process has exactly one HIP runtime: both
+torch's bundled libamdhip64 and /opt/rocm's carry the soname libamdhip64.so.7,
+and the dynamic loader reuses the one already mapped.
+
+There is no CPU fallback: a missing library is an ImportError at first use."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+from . import _build
+
+c_i32, c_i64, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
+
+
+class Layout(ctypes.Structure):
+    """plsr_layout_t"""
+    _fields_ = [("n", c_i32), ("k", c_i32), ("R", c_i32), ("nk", c_i32), ("kp", c_i32),
+                ("period", c_i32), ("Rp", c_i32), ("ntiles", c_i32), ("frag_elems", c_i64)]
+
+
+# every symbol include/plsr.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "plsr_abi_version": (c_i32, []),
+    "plsr_strerror": (ctypes.c_char_p, [c_i32]),
+    "plsr_last_hip_error": (c_i32, []),
+    "plsr_layout_init": (c_i32, [c_i32, c_i32, c_i32, ctypes.POINTER(Layout)]),
+    "plsr_ops_from_indices": (c_i32, [c_vp, c_vp, ctypes.POINTER(Layout), c_vp, c_vp]),
+    "plsr_ops_pack": (c_i32, [c_vp, ctypes.POINTER(Layout), c_vp, c_vp]),
+    "plsr_batch_workspace_bytes": (c_sz, [ctypes.POINTER(Layout), c_i64, c_i32]),
+    "plsr_perm_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,
+                                c_sz, c_vp]),
+    "plsr_boot_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,
+                                c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_boot_finalize": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class PlsrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  plspy_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load()
+        msg = lib.plsr_strerror(rc).decode()
+        raise PlsrError(f"{what}: {msg} (code {rc}, hip error {lib.plsr_last_hip_error()})")

@@ -1,0 +1,360 @@
+// K1: batched operator projection for permutation / bootstrap resamples.
+//
+// One workgroup (4 waves, one per SIMD) owns a tile of PLSR_VOXEL_TILE = 64
+// voxels.  X[:, tile] is staged once in LDS and every resample of the batch is
+// streamed past it:
+//
+//     VS[c, v] = sum_i op_c[i] * X[i, v]        c = (resample, latent variable)
+//
+// as v_mfma_f64_16x16x4_f64 with M = 16 batch columns, N = 16 voxels, K = 4
+// rows of X.  Accumulator layout (cdna guide section 3, f64 map):
+//     D[row = (lane>>4) + 4*reg][col = lane & 15]
+// so a lane's four registers are the four resamples of one quad (same latent
+// variable) at one voxel: the sum over resamples for the bootstrap moments is
+// register-local.  The column norms (s_hat^2) and the k2 x k product with the
+// cell means of X (Tdistrib) contract over voxels, which sit on lanes; the
+// accumulator tile is therefore bounced once through a per-wave LDS patch and
+// re-read as an MFMA A operand (A[m = lane & 15][k = lane >> 4]).
+//
+// Reference arithmetic replaced: bootstrap_permutation.py:404-405 (perm),
+// :617-634 and :695 (boot).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plsr {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TV = 64;         // voxels per workgroup
+constexpr int NT = TV / 16;    // MFMA N-tiles per workgroup
+constexpr int DT_LD = 66;      // padded row of the per-wave transpose patch
+constexpr int WAVES = 4;
+constexpr int MAX_PERIOD = 6;
+
+struct ProjectArgs {
+  const double *X;      // [n][ldx]
+  int64_t ldx;
+  int64_t p;
+  int32_t n, nk;        // nk = ceil(n/4)
+  const double *frag;   // [ntiles][nk][64]
+  int32_t ntiles, k, kp, R, nquads;
+  // outputs
+  double *norm_part;    // [nvt][ntiles*16]
+  double *T_part;       // [nvt][ntiles*16][k2]   (boot, k2 > 0)
+  const double *ref;    // [p][k] or null
+  const double *Xm;     // [k2][ldxm] or null
+  int64_t ldxm;
+  int32_t k2;
+  double *S1, *S2;      // [p][k], accumulated
+  double *vs_dump;      // [R][p][k] or null
+};
+
+__device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// LDS image of the X tile: row i (0 .. 4*nk), 64 voxels; the four 16-voxel
+// blocks of odd rows are stored pairwise swapped so that the two rows one
+// ds_read_b64 half-wave touches fall in different halves of the 64 banks.
+__device__ __forceinline__ int xs_index(int row, int v) {
+  return row * TV + ((((v >> 4) ^ (row & 1)) << 4) | (v & 15));
+}
+
+template <int PERIOD, bool BOOT>
+__global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int64_t vt = blockIdx.x;
+  const int64_t v0 = vt * TV;
+  const int nrows = A.nk * 4;
+
+  double *Xs = smem;                       // nrows * 64
+  double *Dt = smem + (size_t)nrows * TV + (size_t)wave * 16 * DT_LD;
+
+  // ---- stage X[:, v0 : v0+64] (zero padded in both directions) ----
+  for (int r0 = 0; r0 < nrows; r0 += 4 * 4) {
+    double tmp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = r0 + u * 4 + (tid >> 6);
+      const int64_t v = v0 + lane;
+      tmp[u] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = r0 + u * 4 + (tid >> 6);
+      if (row < nrows) Xs[xs_index(row, lane)] = tmp[u];
+    }
+  }
+
+  // per-lane B-operand offsets into Xs for k-step 0: row = g, voxel = 16*nt + col
+  int xo[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) xo[nt] = xs_index(g, nt * 16 + col);
+
+  // second matrix (cell means of X) as B operand of the voxel contraction:
+  // B[k = v = 4*s + g][n = c' = col]
+  double xm[16];
+  double s1[PERIOD][NT], s2[PERIOD][NT], rf[PERIOD][NT];
+  if (BOOT) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int64_t v = v0 + 4 * s + g;
+      xm[s] = (A.Xm != nullptr && col < A.k2 && v < A.p) ? A.Xm[(int64_t)col * A.ldxm + v] : 0.0;
+    }
+#pragma unroll
+    for (int sl = 0; sl < PERIOD; ++sl) {
+      const int j = (4 * sl + g) % A.kp;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int64_t v = v0 + nt * 16 + col;
+        s1[sl][nt] = 0.0;
+        s2[sl][nt] = 0.0;
+        rf[sl][nt] = (A.ref != nullptr && j < A.k && v < A.p) ? A.ref[v * A.k + j] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int64_t C = (int64_t)A.ntiles * 16;
+
+  for (int base = wave * PERIOD; base < A.ntiles; base += WAVES * PERIOD) {
+#pragma unroll
+    for (int sl = 0; sl < PERIOD; ++sl) {
+      const int t = base + sl;
+      if (t >= A.ntiles) break;
+
+      // ---------------- main contraction ----------------
+      f64x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+      const double *ap = A.frag + ((size_t)t * A.nk) * 64 + lane;
+      double an[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) an[u] = (u < A.nk) ? ap[u * 64] : 0.0;
+      for (int s0 = 0; s0 < A.nk; s0 += 4) {
+        double ac[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ac[u] = an[u];
+        const int s1n = s0 + 4;
+        if (s1n < A.nk) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) an[u] = (s1n + u < A.nk) ? ap[(s1n + u) * 64] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (s0 + u < A.nk) {
+            const double *xr = Xs + (size_t)(s0 + u) * 4 * TV;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(ac[u], xr[xo[nt]], acc[nt]);
+          }
+        }
+      }
+
+      // quad / resample bookkeeping of this lane group
+      const int q = 4 * t + g;
+      const int j = q % A.kp;
+      const int bg = q / A.kp;
+      const bool live = (q < A.nquads) && (j < A.k);
+
+      if (BOOT) {
+        // ---------------- streaming moments over resamples ----------------
+        const int nvalid = live ? min(4, A.R - 4 * bg) : 0;   // resamples of this quad that exist
+        if (__builtin_expect(__all(nvalid == 4), 1)) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double d = acc[nt][r] - rf[sl][nt];
+              s1[sl][nt] += d;
+              s2[sl][nt] = fma(d, d, s2[sl][nt]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double d = (r < nvalid) ? acc[nt][r] - rf[sl][nt] : 0.0;
+              s1[sl][nt] += d;
+              s2[sl][nt] = fma(d, d, s2[sl][nt]);
+            }
+          }
+        }
+        if (A.vs_dump != nullptr && live) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int64_t v = v0 + nt * 16 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int b = 4 * bg + r;
+              if (b < A.R && v < A.p) A.vs_dump[((int64_t)b * A.p + v) * A.k + j] = acc[nt][r];
+            }
+          }
+        }
+      }
+
+      // ---------------- voxel contractions via the transpose patch ----------------
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dt[(g + 4 * r) * DT_LD + nt * 16 + col] = acc[nt][r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      double nsq = 0.0;
+      f64x4 accT = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double av = Dt[col * DT_LD + 4 * s + g];
+        nsq = fma(av, av, nsq);
+        if (BOOT) accT = mfma_f64(av, xm[s], accT);
+      }
+      __builtin_amdgcn_wave_barrier();
+      nsq += __shfl_xor(nsq, 16);
+      nsq += __shfl_xor(nsq, 32);
+      if (g == 0) A.norm_part[vt * C + (int64_t)t * 16 + col] = nsq;
+      if (BOOT && A.k2 > 0) {
+        if (col < A.k2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            A.T_part[(vt * C + (int64_t)t * 16 + g + 4 * r) * A.k2 + col] = accT[r];
+        }
+      }
+    }
+  }
+
+  if (BOOT) {
+    // ---- fold the per-wave, per-quad-slot moment registers into S1/S2 ----
+    // scratch[wave][slot][g][v]   (aliases the X tile; all waves are done with it)
+    double *red = smem;
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int sl = 0; sl < PERIOD; ++sl) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          red[((wave * PERIOD + sl) * 4 + g) * TV + nt * 16 + col] = pass == 0 ? s1[sl][nt] : s2[sl][nt];
+      }
+      __syncthreads();
+      double *out = pass == 0 ? A.S1 : A.S2;
+      for (int e = tid; e < TV * A.k; e += 256) {
+        const int vl = e / A.k;
+        const int j = e % A.k;
+        const int64_t v = v0 + vl;
+        if (v >= A.p) continue;
+        double sum = 0.0;
+        for (int w = 0; w < WAVES; ++w) {
+          for (int qq = j; qq < 4 * PERIOD; qq += A.kp)
+            sum += red[((w * PERIOD + (qq >> 2)) * 4 + (qq & 3)) * TV + vl];
+        }
+        out[v * A.k + j] += sum;
+      }
+    }
+  }
+}
+
+inline size_t project_lds_bytes(int nk, int period, bool boot) {
+  size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD) * sizeof(double);
+  size_t b = boot ? (size_t)WAVES * period * 4 * TV * sizeof(double) : 0;
+  return a > b ? a : b;
+}
+
+// ---------------------------------------------------------------------------
+// operator fragments
+// ---------------------------------------------------------------------------
+struct OpsArgs {
+  const int32_t *inds;   // [R][n]            (select mode)
+  const double *M;       // [n][k]            (select mode)
+  const double *cols;    // [R][k][n]         (dense mode)
+  double *frag;          // [ntiles][nk][64]
+  int32_t n, nk, k, kp, R, nquads, ntiles;
+};
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void ops_kernel(OpsArgs A) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)A.ntiles * A.nk * 64;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  const int s = (int)((e >> 6) % A.nk);
+  const int t = (int)((e >> 6) / A.nk);
+  const int m = lane & 15;
+  const int i = 4 * s + (lane >> 4);
+  const int q = 4 * t + (m & 3);
+  const int j = q % A.kp;
+  const int b = 4 * (q / A.kp) + (m >> 2);
+  double val = 0.0;
+  if (q < A.nquads && j < A.k && b < A.R && i < A.n) {
+    if (DENSE) {
+      val = A.cols[((int64_t)b * A.k + j) * A.n + i];
+    } else {
+      const int32_t *ib = A.inds + (int64_t)b * A.n;
+      for (int r = 0; r < A.n; ++r)
+        if (ib[r] == i) val += A.M[(int64_t)r * A.k + j];
+    }
+  }
+  A.frag[e] = val;
+}
+
+// ---------------------------------------------------------------------------
+// slab reductions (deterministic, two-level)
+// ---------------------------------------------------------------------------
+// out[c][e] = sum_{s in chunk c} in[s][e]
+__global__ __launch_bounds__(256) void slab_sum_kernel(const double *in, double *out, int64_t E,
+                                                       int nslab, int chunk) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int c = blockIdx.y;
+  const int s0 = c * chunk;
+  const int s1 = min(nslab, s0 + chunk);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int s = s0;
+  for (; s + 3 < s1; s += 4) {
+    a0 += in[(int64_t)s * E + e];
+    a1 += in[(int64_t)(s + 1) * E + e];
+    a2 += in[(int64_t)(s + 2) * E + e];
+    a3 += in[(int64_t)(s + 3) * E + e];
+  }
+  for (; s < s1; ++s) a0 += in[(int64_t)s * E + e];
+  out[(int64_t)c * E + e] = (a0 + a1) + (a2 + a3);
+}
+
+// final level: sums nslab slabs of [C][w] and scatters tile-ordered columns to
+// resample-major [R][k][w]
+__global__ __launch_bounds__(256) void slab_final_kernel(const double *in, double *out, int64_t C,
+                                                         int w, int nslab, int kp, int k, int R,
+                                                         int nquads) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= C * w) return;
+  const int64_t c = e / w;
+  const int cc = (int)(e % w);
+  const int m = (int)(c & 15);
+  const int64_t q = 4 * (c >> 4) + (m & 3);
+  const int j = (int)(q % kp);
+  const int64_t b = 4 * (q / kp) + (m >> 2);
+  if (q >= nquads || j >= k || b >= R) return;
+  double a = 0.0;
+  for (int s = 0; s < nslab; ++s) a += in[(int64_t)s * C * w + e];
+  out[(b * k + j) * w + cc] = a;
+}
+
+// std / bootstrap-ratio from shifted moments
+__global__ __launch_bounds__(256) void boot_finalize_kernel(const double *S1, const double *S2,
+                                                            const double *num, int64_t count,
+                                                            double invR, double *sd, double *ratio) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  const double m = S1[e] * invR;
+  const double var = fma(-m, m, S2[e] * invR);
+  const double s = sqrt(var > 0.0 ? var : 0.0);
+  sd[e] = s;
+  if (ratio != nullptr) ratio[e] = num[e] / s;
+}
+
+}  // namespace plsr

@@ -1,0 +1,159 @@
+"""Device-side driver of the resampling kernels.
+
+``ProjectionEngine`` keeps X resident in HBM as a torch fp64 tensor and pushes
+batches of resamples through the C-ABI library (include/plsr.h) on torch's
+current HIP stream.  torch is used for memory, streams and (in dist.py)
+torch.distributed only; every arithmetic step on the resampling path is a
+hand-written gfx950 kernel behind the ABI."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ProjectionEngine:
+    """X (n x p, fp64, voxel = unit stride) on one GPU plus scratch.
+
+    work_limit bounds the scratch a single batch may use; larger phases are
+    cut into batches of resamples (each batch is one kernel launch)."""
+
+    def __init__(self, X, device=None, work_limit=6 << 30):
+        if not torch.cuda.is_available():
+            raise RuntimeError("plspy_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        X = torch.as_tensor(X)
+        if X.dim() != 2:
+            raise ValueError("X must be 2-dimensional")
+        self.X = X.to(device=self.device, dtype=torch.float64).contiguous()
+        self.n, self.p = self.X.shape
+        self.work_limit = int(work_limit)
+        self._work = None
+        self._frag = None
+
+    # -- helpers -----------------------------------------------------------
+    def dev(self, a, dtype=torch.float64):
+        if a is None:
+            return None
+        return torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(
+            device=self.device, dtype=dtype).contiguous()
+
+    def layout(self, k, R):
+        lay = _lib.Layout()
+        _lib.check(self.lib.plsr_layout_init(self.n, k, R, ctypes.byref(lay)),
+                   f"plsr_layout_init(n={self.n}, k={k}, R={R})")
+        return lay
+
+    def batch_size(self, k, k2, R):
+        """Largest multiple-of-4 batch whose scratch fits work_limit."""
+        lay = self.layout(k, 4)
+        per4 = self.lib.plsr_batch_workspace_bytes(ctypes.byref(lay), self.p, k2)
+        per4 += lay.frag_elems * 8
+        nb = max(1, self.work_limit // max(per4, 1))
+        return int(min((R + 3) // 4 * 4, nb * 4))
+
+    def _scratch(self, lay, k2):
+        need = self.lib.plsr_batch_workspace_bytes(ctypes.byref(lay), self.p, k2)
+        if self._work is None or self._work.numel() < need:
+            self._work = None
+            self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self._frag is None or self._frag.numel() < lay.frag_elems:
+            self._frag = None
+            self._frag = torch.empty(lay.frag_elems, dtype=torch.float64, device=self.device)
+        return self._work, self._frag, need
+
+    def _build_ops(self, lay, frag, inds=None, M=None, cols=None):
+        if cols is not None:
+            _lib.check(self.lib.plsr_ops_pack(_ptr(cols), ctypes.byref(lay), _ptr(frag), _stream()),
+                       "plsr_ops_pack")
+        else:
+            _lib.check(self.lib.plsr_ops_from_indices(_ptr(inds), _ptr(M), ctypes.byref(lay),
+                                                      _ptr(frag), _stream()),
+                       "plsr_ops_from_indices")
+
+    # -- permutation ---------------------------------------------------------
+    def perm_phase(self, k, inds=None, M=None, cols=None):
+        """s_hat^2 (R x k) for every resample.  Either ``inds`` (R x n int32
+        row selections) with ``M`` (n x k), or dense ``cols`` (R x k x n)."""
+        R = int(inds.shape[0] if inds is not None else cols.shape[0])
+        out = torch.empty((R, k), dtype=torch.float64, device=self.device)
+        if R == 0:
+            return out
+        step = self.batch_size(k, 0, R)
+        Md = self.dev(M)
+        for lo in range(0, R, step):
+            hi = min(R, lo + step)
+            lay = self.layout(k, hi - lo)
+            work, frag, need = self._scratch(lay, 0)
+            if cols is not None:
+                self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
+            else:
+                self._build_ops(lay, frag, inds=self.dev(inds[lo:hi], torch.int32), M=Md)
+            _lib.check(self.lib.plsr_perm_batch(_ptr(self.X), self.X.stride(0), self.p, _ptr(frag),
+                                                ctypes.byref(lay), _ptr(out[lo:hi]), _ptr(work),
+                                                need, _stream()), "plsr_perm_batch")
+        return out
+
+    # -- bootstrap -----------------------------------------------------------
+    def boot_phase(self, k, inds=None, M=None, cols=None, ref=None, Xm=None, dump=False):
+        """Streams a bootstrap phase.  Returns dict(S1, S2 (p x k shifted
+        moments), ssq (R x k), T (R x k x k2) or None, vs (R x p x k) or None)."""
+        R = int(inds.shape[0] if inds is not None else cols.shape[0])
+        refd = self.dev(ref)
+        Xmd = self.dev(Xm)
+        k2 = 0 if Xmd is None else int(Xmd.shape[0])
+        S1 = torch.zeros((self.p, k), dtype=torch.float64, device=self.device)
+        S2 = torch.zeros_like(S1)
+        ssq = torch.empty((R, k), dtype=torch.float64, device=self.device)
+        T = torch.empty((R, k, k2), dtype=torch.float64, device=self.device) if k2 else None
+        vs = torch.zeros((R, self.p, k), dtype=torch.float64, device=self.device) if dump else None
+        if R:
+            step = self.batch_size(k, k2, R)
+            Md = self.dev(M)
+            for lo in range(0, R, step):
+                hi = min(R, lo + step)
+                lay = self.layout(k, hi - lo)
+                work, frag, need = self._scratch(lay, k2)
+                if cols is not None:
+                    self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
+                else:
+                    self._build_ops(lay, frag, inds=self.dev(inds[lo:hi], torch.int32), M=Md)
+                _lib.check(self.lib.plsr_boot_batch(
+                    _ptr(self.X), self.X.stride(0), self.p, _ptr(frag), ctypes.byref(lay),
+                    _ptr(refd), _ptr(Xmd), Xmd.stride(0) if k2 else 0, k2,
+                    _ptr(S1), _ptr(S2), _ptr(ssq[lo:hi]), _ptr(T[lo:hi]) if k2 else _ptr(None),
+                    _ptr(vs[lo:hi]) if dump else _ptr(None), _ptr(work), need, _stream()),
+                    "plsr_boot_batch")
+        return {"S1": S1, "S2": S2, "ssq": ssq, "T": T, "vs": vs, "R": R}
+
+    def boot_finalize(self, S1, S2, R, num=None):
+        """(std_errs, boot_ratios) from summed shifted moments."""
+        sd = torch.empty_like(S1)
+        ratio = torch.empty_like(S1) if num is not None else None
+        numd = self.dev(num)
+        _lib.check(self.lib.plsr_boot_finalize(_ptr(S1), _ptr(S2), _ptr(numd), S1.numel(), int(R),
+                                               _ptr(sd), _ptr(ratio), _stream()),
+                   "plsr_boot_finalize")
+        return sd, ratio
+
+    def apply_operator(self, rows):
+        """(m x n) operator rows -> (m x p) = rows @ X, through the projection
+        kernel (used for the observed cell means / centred block)."""
+        rows = np.asarray(rows, dtype=float)
+        m = rows.shape[0]
+        out = []
+        for lo in range(0, m, 16):
+            blk = rows[lo:lo + 16]
+            res = self.boot_phase(blk.shape[0], cols=blk[None, :, :], dump=True)
+            out.append(res["vs"][0].T)
+        return torch.cat(out, dim=0)

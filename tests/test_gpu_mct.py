@@ -1,0 +1,151 @@
+"""GPU parity for mean-centring task PLS: the HIP path (through the C ABI)
+against (1) the golden vectors from the reference and (2) the NumPy oracle on
+identical random draws.  Tolerances: s_hat 1e-10 rel, permutation counts exact,
+bootstrap statistics 1e-9 rel on non-null latent variables."""
+import numpy as np
+import pytest
+
+from oracle import plspy_oracle as orc
+from tests._util import assert_close, golden_names, load_golden, nonnull, run_oracle_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_seam(fx, **kw):
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    X, co = fx["X"], fx["cond_order"]
+    Tv = orc.group_condition_means(X @ fx["V"], co)
+    np.random.seed(fx["seed"])
+    return ResampleTest._create("mct", X, None, fx["U"], fx["s"].copy(), fx["V"], co, fx["mctype"],
+                                nperm=fx["nperm"], nboot=fx["nboot"], Tvsc_orig=Tv,
+                                keep_right_sv=True, **kw)
+
+
+@pytest.fixture(scope="module", params=golden_names("mct_g"))
+def case(request):
+    fx = load_golden(request.param)
+    return fx, _run_seam(fx)
+
+
+def test_perm_against_reference(case):
+    fx, rt = case
+    assert_close(rt.perm_debug_dict["s_list"], fx["s_list"], 1e-10, 1e-11, "s_list")
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(rt.permute_ratio * n1), np.rint(fx["permute_ratio"] * n1))
+    np.testing.assert_array_equal(np.rint(rt.stepdown_ratio * n1), np.rint(fx["stepdown_ratio"] * n1))
+
+
+def test_boot_against_reference(case):
+    fx, rt = case
+    live = nonnull(fx)
+    dbg = rt.boot_debug_dict
+    assert_close(dbg["right_sv_sampled"], fx["right_sv_sampled"], 1e-10, 1e-12, "right_sv_sampled")
+    assert_close(dbg["left_sv_sampled"], fx["left_sv_sampled"], 1e-9, 1e-12, "left_sv_sampled")
+    assert_close(rt.std_errs[:, live], fx["std_errs"][:, live], 1e-9, 1e-13, "std_errs")
+    assert_close(rt.boot_ratios[:, live], fx["boot_ratios"][:, live], 1e-8, 1e-10, "boot_ratios")
+    assert_close(rt.conf_ints[0][:, live], fx["conf_lo"][:, live], 1e-9, 1e-12, "conf lo")
+    assert_close(rt.conf_ints[1][:, live], fx["conf_hi"][:, live], 1e-9, 1e-12, "conf hi")
+
+
+def test_against_oracle_same_draws(case):
+    fx, rt = case
+    np.random.seed(fx["seed"])
+    out = run_oracle_case(fx)
+    assert_close(rt.perm_debug_dict["s_list"], out["perm"]["s_list"], 1e-10, 1e-11, "s_list")
+    np.testing.assert_array_equal(rt.permute_ratio, out["perm"]["permute_ratio"])
+    np.testing.assert_array_equal(rt.stepdown_ratio, out["perm"]["stepdown_ratio"])
+    live = nonnull(fx)
+    assert_close(rt.std_errs[:, live], out["boot"]["std_errs"][:, live], 1e-9, 1e-13, "std_errs")
+    assert_close(rt.boot_debug_dict["Tdistrib"][:, :, live], out["boot"]["Tdistrib"][:, :, live],
+                 1e-9, 1e-12, "Tdistrib")
+
+
+@pytest.mark.parametrize("name", ["mct_g10x10_c3_mc0", "mct_g3x2_c2", "mct_g8_c3_mc1"])
+def test_full_pls_call(name):
+    """plspy_amd.PLS(...) end to end against the reference's result object
+    (per-LV sign alignment; null LVs' vectors excluded)."""
+    import plspy_amd
+    fx = load_golden(name)
+    np.random.seed(fx["seed"])
+    res = plspy_amd.PLS(fx["X"].copy(), fx["groups"], fx["ncond"], num_perm=fx["nperm"],
+                        num_boot=fx["nboot"], mctype=fx["mctype"], pls_method="mct")
+    live = nonnull(fx)
+    # after the swap res.U is p x k (voxel saliences), res.V is k x k
+    sign = np.sign(np.sum(res.V[:, live] * fx["U"][:, live], axis=0))
+    assert_close(res.s[live], fx["s"][live], 1e-10, 0, "s")
+    assert_close(res.V[:, live] * sign, fx["U"][:, live], 1e-8, 1e-10, "U (design saliences)")
+    assert_close(res.U[:, live] * sign, fx["V"][:, live], 1e-8, 1e-10, "V (voxel saliences)")
+    assert_close(res.X_mc, fx["X_mc"], 1e-10, 1e-12, "X_mc")
+    assert_close(res.X_means, fx["X_means"], 1e-10, 1e-12, "X_means")
+    rt = res.resample_tests
+    assert_close(rt.perm_debug_dict["s_list"][:, live], fx["s_list"][:, live], 1e-9, 1e-11, "s_list")
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(rt.permute_ratio * n1)[live], np.rint(fx["permute_ratio"] * n1)[live])
+    assert_close(rt.std_errs[:, live], fx["std_errs"][:, live], 1e-8, 1e-12, "std_errs")
+    assert_close(rt.boot_ratios[:, live] * sign, fx["boot_ratios"][:, live], 1e-7, 1e-9, "boot_ratios")
+
+
+def test_ragged_and_padding_shapes():
+    """Voxel counts off the 64-voxel tile, resample counts off the quad size,
+    and latent-variable counts that need padding (k = 7 -> 8, k = 9 -> 12)."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    rs = np.random.RandomState(0)
+    for groups, nc, p, nperm, nboot in [((7,), 7, 1, 3, 5), ((3, 3, 3), 3, 65, 1, 2),
+                                        ((5, 4), 1, 129, 6, 7), ((2, 2), 2, 63, 4, 4)]:
+        co = np.array([[g] * nc for g in groups])
+        n = co.sum()
+        X = rs.randn(n, p) + rs.randn(1, p)
+        mctype = 1 if nc == 1 else 0
+        obs = orc.observed("mct", X, co, mctype=mctype)
+        U, s, V = obs["U"], obs["s"], obs["V"]
+        np.random.seed(5)
+        rec = orc.RecordingSampler()
+        perm = orc.permutation_test("mct", X, None, U, s, V, co, mctype, nperm, sampler=rec)
+        boot = orc.bootstrap_test("mct", X, None, U, perm["s"], V, co, mctype, nboot,
+                                  Tvsc_orig=obs["Tvsc_orig"], sampler=rec)
+        np.random.seed(5)
+        rt = ResampleTest._create("mct", X, None, U, s.copy(), V, co, mctype, nperm=nperm,
+                                  nboot=nboot, Tvsc_orig=obs["Tvsc_orig"], keep_right_sv=True)
+        assert_close(rt.perm_debug_dict["s_list"], perm["s_list"], 1e-10, 1e-11, f"s_list {groups}")
+        assert_close(rt.boot_debug_dict["right_sv_sampled"], boot["right_sv_sampled"], 1e-10, 1e-12,
+                     f"right_sv {groups}")
+        live = np.where(perm["s"] > 0)[0]
+        assert_close(rt.std_errs[:, live], boot["std_errs"][:, live], 1e-9, 1e-13, f"std {groups}")
+
+
+def test_full_size_properties():
+    """BASELINE config 2 shape (60 x 200 000) with few resamples: checks that do
+    not need the oracle to run at full size.
+      * sum_j s_hat_j^2 == ||W P X||_F^2, evaluated p-free through G = X X^T
+        (the Gram identity of SURVEY.md H6, used here only as a cross-check);
+      * std_errs on a random voxel subset == np.std of the directly computed
+        projections of that subset."""
+    import torch
+    from plspy_amd import operators, resample
+    from plspy_amd.engine import ProjectionEngine
+    groups, nc, p = (10, 10), 3, 200_000
+    co = np.array([[g] * nc for g in groups])
+    X = np.random.RandomState(0).randn(60, p)
+    W = operators.mean_centre_operator(co, 0)
+    U, s, Vt = np.linalg.svd(W @ X, full_matrices=False)
+    eng = ProjectionEngine(X)
+    np.random.seed(1234)
+    inds = resample.task_permutations(co, 12)
+    ssq = eng.perm_phase(6, inds=inds, M=W.T @ U).cpu().numpy()
+    G = X @ X.T
+    for b in range(len(inds)):
+        P = np.zeros((60, 60))
+        P[np.arange(60), inds[b]] = 1
+        A = W @ P
+        np.testing.assert_allclose(ssq[b].sum(), np.trace(A @ G @ A.T), rtol=1e-11)
+    binds = resample.bootstraps(co, 10)
+    ref = Vt.T * s
+    res = eng.boot_phase(6, inds=binds, M=W.T @ U, ref=ref)
+    sd, _ = eng.boot_finalize(res["S1"], res["S2"], 10, num=ref)
+    sub = np.random.RandomState(3).choice(p, 500, replace=False)
+    sub = np.concatenate((sub, [0, 63, 64, p - 1]))
+    direct = np.stack([(W @ X[binds[b]][:, sub]).T @ U for b in range(10)])
+    live = s > 1e-10 * s.max()
+    np.testing.assert_allclose(sd.cpu().numpy()[sub][:, live], np.std(direct, axis=0)[:, live],
+                               rtol=1e-9, atol=1e-13)
+    torch.cuda.synchronize()

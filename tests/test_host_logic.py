@@ -1,0 +1,107 @@
+"""CPU-side pieces of the product: index draws, operators, the C-ABI's host
+entry points, sharding arithmetic.  No GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import plspy_oracle as orc
+from plspy_amd import _build, _lib, dist, operators, resample
+from tests._util import golden_names, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _build.build()
+    return _lib.load()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "plsr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(plsr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.plsr_abi_version() == 1
+    assert lib.plsr_strerror(0) == b"ok"
+
+
+@pytest.mark.parametrize("k,kp,period", [(1, 1, 1), (2, 2, 1), (3, 3, 3), (4, 4, 1), (5, 5, 5),
+                                         (6, 6, 3), (7, 8, 2), (9, 12, 3), (12, 12, 3), (24, 24, 6)])
+def test_layout(lib, k, kp, period):
+    lay = _lib.Layout()
+    assert lib.plsr_layout_init(60, k, 10, ctypes.byref(lay)) == 0
+    assert (lay.kp, lay.period, lay.nk, lay.Rp) == (kp, period, 15, 12)
+    assert (4 * lay.period) % lay.kp == 0          # the slot -> latent-variable map repeats
+    assert lay.ntiles == -(-(lay.kp * lay.Rp // 4) // 4)
+    assert lay.frag_elems == lay.ntiles * lay.nk * 64
+
+
+def test_layout_rejects(lib):
+    lay = _lib.Layout()
+    assert lib.plsr_layout_init(0, 6, 10, ctypes.byref(lay)) == -1
+    assert lib.plsr_layout_init(60, 6, 0, ctypes.byref(lay)) == -1
+    assert lib.plsr_layout_init(2000, 6, 10, ctypes.byref(lay)) == -2     # X tile > LDS
+    assert lib.plsr_batch_workspace_bytes(None, 10, 0) == 0
+
+
+@pytest.mark.parametrize("mctype", [0, 1, 2, 3])
+@pytest.mark.parametrize("groups,nc", [((10, 10), 3), ((3, 2), 2), ((8,), 3), ((4, 5, 6), 2)])
+def test_mean_centre_operator_matches_oracle(groups, nc, mctype):
+    co = np.array([[g] * nc for g in groups])
+    n = co.sum()
+    X = np.random.RandomState(1).randn(n, 17)
+    W = operators.mean_centre_operator(co, mctype)
+    Wm = operators.cell_mean_operator(co)
+    means, mc = orc.mean_centre(X, co, mctype)
+    np.testing.assert_allclose(W @ X, mc, rtol=0, atol=2e-15)
+    np.testing.assert_allclose(Wm @ X, means, rtol=0, atol=2e-15)
+    # resample folds into the operator (appendix A2)
+    inds = np.random.RandomState(2).randint(0, n, n)
+    P = np.zeros((n, n))
+    P[np.arange(n), inds] = 1
+    np.testing.assert_allclose((W @ P) @ X, orc.mean_centre(X[inds], co, mctype)[1], atol=3e-15)
+
+
+@pytest.mark.parametrize("name", golden_names("mct_g"))
+def test_index_draws_match_reference(name):
+    """Same seed -> the same resamples as the reference drew (the fixture holds
+    the reference's raw np.random outputs)."""
+    fx = load_golden(name)
+    co = fx["cond_order"]
+    np.random.seed(fx["seed"])
+    perm = resample.task_permutations(co, fx["nperm"])
+    boot = resample.bootstraps(co, fx["nboot"])
+    np.random.seed(fx["seed"])
+    smp = orc.Sampler()
+    for i in range(fx["nperm"]):
+        np.testing.assert_array_equal(perm[i], smp.perm_task(co))
+    for i in range(fx["nboot"]):
+        np.testing.assert_array_equal(boot[i], smp.boot(co))
+    # and against the raw reference stream: the last per-condition shuffle of
+    # the first permutation is a permutation of that condition's rows
+    nsub, nc = sum(fx["groups"]), fx["ncond"]
+    raw = fx["draws"]
+    first = np.stack(raw[nsub:nsub + nc]).ravel()
+    np.testing.assert_array_equal(perm[0], first)
+    # bootstrap rows: per group, reference's choice() output indexes the table
+    off = fx["nperm"] * (nsub + nc)
+    tables = resample.subject_tables(co)
+    expect = np.concatenate([t[raw[off + g]].T.ravel() for g, t in enumerate(tables)])
+    np.testing.assert_array_equal(boot[0], expect)
+
+
+def test_shard_bounds_cover():
+    for R in (0, 1, 7, 1000):
+        for n in (1, 2, 3, 8):
+            b = [dist.shard_bounds(R, r, n) for r in range(n)]
+            assert b[0][0] == 0 and b[-1][1] == R
+            assert all(b[i][1] == b[i + 1][0] for i in range(n - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
