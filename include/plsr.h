@@ -125,6 +125,17 @@ int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p,
 int plsr_boot_finalize(const double *d_S1, const double *d_S2, const double *d_num,
                        int64_t count, int32_t R, double *d_std, double *d_ratio, void *stream);
 
+/*
+ * Kernel timing for the roofline report (bench.py).  When enabled, every
+ * projection-kernel launch made by plsr_perm_batch / plsr_boot_batch is
+ * bracketed by hipEvents recorded on the launch stream.  plsr_timing_collect
+ * synchronises those events and returns the elapsed milliseconds of each launch
+ * since the last collect (kind[i] = 0 perm, 1 boot), at most `max` of them.
+ * Not for use inside a graph capture.
+ */
+int plsr_timing_enable(int on);
+int plsr_timing_collect(double *ms_out, int32_t *kind_out, int32_t max);
+
 #ifdef __cplusplus
 }
 #endif

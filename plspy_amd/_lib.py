@@ -36,6 +36,8 @@ SIGNATURES = {
     "plsr_boot_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,
                                 c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_boot_finalize": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "plsr_timing_enable": (c_i32, [c_i32]),
+    "plsr_timing_collect": (c_i32, [c_vp, c_vp, c_i32]),
 }
 
 _lib = None

@@ -6,10 +6,21 @@
 
 #include <algorithm>
 #include <numeric>
+#include <vector>
 
 using namespace plsr;
 
 static thread_local int g_last_hip = 0;
+
+// optional per-launch timing of the projection kernel (plsr_timing_*)
+namespace {
+struct TimedLaunch {
+  hipEvent_t a, b;
+  int kind;
+};
+bool g_timing = false;
+std::vector<TimedLaunch> g_timed;
+}  // namespace
 
 static inline int check_launch() {
   hipError_t e = hipGetLastError();
@@ -141,13 +152,13 @@ int reduce_slabs(const double *slabs, const Work &w, int width, const plsr_layou
   return check_launch();
 }
 
-template <bool BOOT>
+template <int MODE>
 int launch_project(const ProjectArgs &a, int period, int64_t nvt, hipStream_t st) {
-  const size_t lds = project_lds_bytes(a.nk, period, BOOT);
+  const size_t lds = project_lds_bytes(a.nk, period, MODE != 0);
   dim3 grid((unsigned)nvt), block(256);
 #define PLSR_CASE(P)                                                                          \
   case P: {                                                                                   \
-    auto kern = project_kernel<P, BOOT>;                                                      \
+    auto kern = project_kernel<P, MODE>;                                                      \
     if (lds > 64 * 1024) {                                                                    \
       hipError_t e = hipFuncSetAttribute((const void *)kern,                                  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -156,7 +167,18 @@ int launch_project(const ProjectArgs &a, int period, int64_t nvt, hipStream_t st
         return PLSR_ELAUNCH;                                                                  \
       }                                                                                       \
     }                                                                                         \
+    TimedLaunch tl{};                                                                         \
+    if (g_timing) {                                                                           \
+      (void)hipEventCreate(&tl.a);                                                                  \
+      (void)hipEventCreate(&tl.b);                                                                  \
+      tl.kind = MODE;                                                                 \
+      (void)hipEventRecord(tl.a, st);                                                               \
+    }                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                        \
+    if (g_timing) {                                                                           \
+      (void)hipEventRecord(tl.b, st);                                                               \
+      g_timed.push_back(tl);                                                                  \
+    }                                                                                         \
     break;                                                                                    \
   }
   switch (period) {
@@ -208,7 +230,7 @@ extern "C" int plsr_perm_batch(const double *d_X, int64_t ldx, int64_t p, const 
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
   hipStream_t st = (hipStream_t)stream;
-  rc = launch_project<false>(a, lay->period, w.nvt, st);
+  rc = launch_project<0>(a, lay->period, w.nvt, st);
   if (rc) return rc;
   return reduce_slabs(w.norm_part, w, 1, lay, d_ssq, st);
 }
@@ -236,7 +258,8 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   a.S2 = d_S2;
   a.vs_dump = d_vs_dump;
   hipStream_t st = (hipStream_t)stream;
-  rc = launch_project<true>(a, lay->period, w.nvt, st);
+  rc = d_vs_dump ? launch_project<2>(a, lay->period, w.nvt, st)
+                 : launch_project<1>(a, lay->period, w.nvt, st);
   if (rc) return rc;
   rc = reduce_slabs(w.norm_part, w, 1, lay, d_ssq, st);
   if (rc) return rc;
@@ -253,4 +276,27 @@ extern "C" int plsr_boot_finalize(const double *d_S1, const double *d_S2, const 
   hipLaunchKernelGGL(boot_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_S1, d_S2,
                      d_num, count, 1.0 / (double)R, d_std, d_ratio);
   return check_launch();
+}
+
+extern "C" int plsr_timing_enable(int on) {
+  g_timing = on != 0;
+  return PLSR_OK;
+}
+
+extern "C" int plsr_timing_collect(double *ms_out, int32_t *kind_out, int32_t max) {
+  int n = 0;
+  for (auto &tl : g_timed) {
+    (void)hipEventSynchronize(tl.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, tl.a, tl.b);
+    if (n < max && ms_out) {
+      ms_out[n] = ms;
+      if (kind_out) kind_out[n] = tl.kind;
+      ++n;
+    }
+    (void)hipEventDestroy(tl.a);
+    (void)hipEventDestroy(tl.b);
+  }
+  g_timed.clear();
+  return n;
 }

@@ -61,8 +61,12 @@ __device__ __forceinline__ int xs_index(int row, int v) {
   return row * TV + ((((v >> 4) ^ (row & 1)) << 4) | (v & 15));
 }
 
-template <int PERIOD, bool BOOT>
+// MODE 0: permutation (norms only); 1: bootstrap (moments, norms, T);
+// 2: bootstrap that also materialises VS (tests, debug dict, observed blocks)
+template <int PERIOD, int MODE>
 __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
+  constexpr bool BOOT = MODE != 0;
+  constexpr bool DUMP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
             }
           }
         }
-        if (A.vs_dump != nullptr && live) {
+        if (DUMP && A.vs_dump != nullptr && live) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int64_t v = v0 + nt * 16 + col;
