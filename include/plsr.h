@@ -126,6 +126,34 @@ int plsr_boot_finalize(const double *d_S1, const double *d_S2, const double *d_n
                        int64_t count, int32_t R, double *d_std, double *d_ratio, void *stream);
 
 /*
+ * ---- K2: cross-block Gram and thin SVD -------------------------------------
+ * An item is one decomposition request: m operator rows A (m x n) whose
+ * cross-block M = A X (m x p) is never stored.  Replaces _run_pls ->
+ * np.linalg.svd (class_functions.py:98-123) as used by
+ * split_half_resampling.py:194-196, :612-613, :682-683 and pls_classes.py:261:
+ * with G = M M^T = U S^2 U^T,  s = sqrt(eig), V = M^T U / s.
+ */
+/* doubles in the fragment buffer for `items` items of m rows */
+int64_t plsr_rows_frag_elems(int32_t n, int32_t m, int32_t items);
+/* d_rows[item][j][i] (items x m x n fp64) -> MFMA operand fragments */
+int plsr_ops_pack_rows(const double *d_rows, int32_t items, int32_t m, int32_t n,
+                       double *d_frag, void *stream);
+size_t plsr_gram_workspace_bytes(int32_t n, int32_t m, int32_t items, int64_t p);
+/* d_G[item][mm][mm], mm = 16*ceil(m/16); rows/cols >= m are zero */
+int plsr_gram_batch(const double *d_X, int64_t ldx, int64_t p, int32_t n,
+                    const double *d_frag, int32_t items, int32_t m, double *d_G,
+                    void *d_work, size_t work_bytes, void *stream);
+/*
+ * Symmetric eigen-decomposition of the k x k block at (off, off) of each of
+ * `count` matrices (leading dimension ld, item_stride doubles apart): one
+ * wavefront per matrix, cyclic Jacobi in LDS.  Eigenvalues descending in
+ * d_evals[item][k]; eigenvectors in the columns of d_evecs[item][k][k].
+ * k <= 64.
+ */
+int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t ld, int32_t off,
+                    int32_t k, int32_t count, double *d_evals, double *d_evecs, void *stream);
+
+/*
  * Kernel timing for the roofline report (bench.py).  When enabled, every
  * projection-kernel launch made by plsr_perm_batch / plsr_boot_batch is
  * bracketed by hipEvents recorded on the launch stream.  plsr_timing_collect

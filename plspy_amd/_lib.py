@@ -36,6 +36,11 @@ SIGNATURES = {
     "plsr_boot_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,
                                 c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_boot_finalize": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "plsr_rows_frag_elems": (c_i64, [c_i32, c_i32, c_i32]),
+    "plsr_ops_pack_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "plsr_gram_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
+    "plsr_gram_batch": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_eigh_batch": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "plsr_timing_enable": (c_i32, [c_i32]),
     "plsr_timing_collect": (c_i32, [c_vp, c_vp, c_i32]),
 }
@@ -52,7 +57,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("PLSR_LIB", _build.LIB)   # PLSR_LIB: developer override (ablation builds)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

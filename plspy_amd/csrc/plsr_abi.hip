@@ -53,7 +53,6 @@ extern "C" int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *
     kp = (k + 3) / 4 * 4;
     period = kp / 4;
   }
-  if (period > MAX_PERIOD) return PLSR_EUNSUPPORTED;
   out->n = n;
   out->k = k;
   out->R = R;
@@ -65,7 +64,7 @@ extern "C" int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *
   out->ntiles = (int32_t)((nquads + 3) / 4);
   out->frag_elems = (int64_t)out->ntiles * out->nk * 64;
   // the X tile plus the transpose patches must fit the 160 KiB LDS of a CU
-  if (project_lds_bytes(out->nk, period, true) > 160 * 1024) return PLSR_EUNSUPPORTED;
+  if (project_lds_bytes(out->nk, std::min(period, MAX_PERIOD), true) > 160 * 1024) return PLSR_EUNSUPPORTED;
   return PLSR_OK;
 }
 
@@ -114,6 +113,8 @@ namespace {
 constexpr int SLAB_CHUNK = 64;
 
 struct Work {
+  double *mom_part;    // [2][nsplit][p][k]   (boot)
+  int nsplit;          // column splits of the batch (grid.y)
   double *norm_part;   // [nvt][C]
   double *T_part;      // [nvt][C][k2]
   double *lvl2;        // [nchunk][C*max(1,k2)]
@@ -122,10 +123,29 @@ struct Work {
   size_t bytes;
 };
 
-Work carve(const plsr_layout_t *lay, int64_t p, int32_t k2, void *base) {
+// column splits: pick the grid.y in 1..4 that wastes least in the last round of
+// workgroups (256 CUs x 2 resident workgroups), without splitting below one
+// wave x period group per workgroup
+int pick_split(const plsr_layout_t *lay, int64_t nvt) {
+  const int groups = (lay->ntiles + WAVES * lay->period - 1) / (WAVES * lay->period);
+  int best = 1;
+  double best_eff = 0.0;
+  for (int c = 1; c <= 4 && c <= groups; ++c) {
+    const double rounds = (double)nvt * c / 512.0;
+    const double eff = rounds / std::ceil(rounds);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = c;
+    }
+  }
+  return best;
+}
+
+Work carve(const plsr_layout_t *lay, int64_t p, int32_t k2, void *base, bool boot) {
   Work w;
   w.nvt = (p + TV - 1) / TV;
   w.C = (int64_t)lay->ntiles * 16;
+  w.nsplit = pick_split(lay, w.nvt);
   w.nchunk = (int)((w.nvt + SLAB_CHUNK - 1) / SLAB_CHUNK);
   size_t off = 0;
   auto take = [&](size_t elems) {
@@ -133,6 +153,7 @@ Work carve(const plsr_layout_t *lay, int64_t p, int32_t k2, void *base) {
     off += (elems * sizeof(double) + 255) / 256 * 256;
     return ptr;
   };
+  w.mom_part = boot ? take((size_t)2 * w.nsplit * p * lay->k) : nullptr;
   w.norm_part = take((size_t)w.nvt * w.C);
   w.T_part = k2 > 0 ? take((size_t)w.nvt * w.C * k2) : nullptr;
   w.lvl2 = take((size_t)w.nchunk * w.C * std::max(1, (int)k2));
@@ -153,9 +174,9 @@ int reduce_slabs(const double *slabs, const Work &w, int width, const plsr_layou
 }
 
 template <int MODE>
-int launch_project(const ProjectArgs &a, int period, int64_t nvt, hipStream_t st) {
+int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hipStream_t st) {
   const size_t lds = project_lds_bytes(a.nk, period, MODE != 0);
-  dim3 grid((unsigned)nvt), block(256);
+  dim3 grid((unsigned)nvt, (unsigned)nsplit), block(256);
 #define PLSR_CASE(P)                                                                          \
   case P: {                                                                                   \
     auto kern = project_kernel<P, MODE>;                                                      \
@@ -197,13 +218,12 @@ int launch_project(const ProjectArgs &a, int period, int64_t nvt, hipStream_t st
 
 extern "C" size_t plsr_batch_workspace_bytes(const plsr_layout_t *lay, int64_t p, int32_t k2) {
   if (!lay || p <= 0 || k2 < 0) return 0;
-  return carve(lay, p, k2, nullptr).bytes;
+  return carve(lay, p, k2, nullptr, true).bytes;
 }
 
 static int fill_common(ProjectArgs &a, const double *d_X, int64_t ldx, int64_t p,
                        const double *d_frag, const plsr_layout_t *lay) {
   if (!d_X || !d_frag || !lay || p <= 0 || ldx < p) return PLSR_EINVAL;
-  if (lay->period < 1 || lay->period > MAX_PERIOD) return PLSR_EUNSUPPORTED;
   a = ProjectArgs{};
   a.X = d_X;
   a.ldx = ldx;
@@ -226,11 +246,13 @@ extern "C" int plsr_perm_batch(const double *d_X, int64_t ldx, int64_t p, const 
   int rc = fill_common(a, d_X, ldx, p, d_frag, lay);
   if (rc) return rc;
   if (!d_ssq || !d_work) return PLSR_EINVAL;
-  Work w = carve(lay, p, 0, d_work);
+  Work w = carve(lay, p, 0, d_work, false);
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
   hipStream_t st = (hipStream_t)stream;
-  rc = launch_project<0>(a, lay->period, w.nvt, st);
+  // the permutation kernel keeps no per-latent-variable registers, so the
+  // period-1 instance serves every k
+  rc = launch_project<0>(a, 1, w.nvt, w.nsplit, st);
   if (rc) return rc;
   return reduce_slabs(w.norm_part, w, 1, lay, d_ssq, st);
 }
@@ -246,7 +268,8 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   if (!d_S1 || !d_S2 || !d_ssq || !d_work) return PLSR_EINVAL;
   if (k2 < 0 || k2 > 16) return PLSR_EUNSUPPORTED;
   if (k2 > 0 && (!d_Xm || !d_T || ldxm < p)) return PLSR_EINVAL;
-  Work w = carve(lay, p, k2, d_work);
+  if (lay->period < 1 || lay->period > MAX_PERIOD) return PLSR_EUNSUPPORTED;
+  Work w = carve(lay, p, k2, d_work, true);
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
   a.T_part = w.T_part;
@@ -254,13 +277,21 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   a.Xm = k2 > 0 ? d_Xm : nullptr;
   a.ldxm = ldxm;
   a.k2 = k2;
-  a.S1 = d_S1;
-  a.S2 = d_S2;
+  a.S1 = w.mom_part;
+  a.S2 = w.mom_part + (size_t)w.nsplit * p * lay->k;
   a.vs_dump = d_vs_dump;
   hipStream_t st = (hipStream_t)stream;
-  rc = d_vs_dump ? launch_project<2>(a, lay->period, w.nvt, st)
-                 : launch_project<1>(a, lay->period, w.nvt, st);
+  rc = d_vs_dump ? launch_project<2>(a, lay->period, w.nvt, w.nsplit, st)
+                 : launch_project<1>(a, lay->period, w.nvt, w.nsplit, st);
   if (rc) return rc;
+  {
+    const int64_t cnt = p * lay->k;
+    dim3 g((unsigned)((cnt + 255) / 256));
+    hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S1, (const double *)a.S1, cnt,
+                       w.nsplit);
+    hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S2, (const double *)a.S2, cnt,
+                       w.nsplit);
+  }
   rc = reduce_slabs(w.norm_part, w, 1, lay, d_ssq, st);
   if (rc) return rc;
   if (k2 > 0) rc = reduce_slabs(w.T_part, w, k2, lay, d_T, st);
@@ -299,4 +330,133 @@ extern "C" int plsr_timing_collect(double *ms_out, int32_t *kind_out, int32_t ma
   }
   g_timed.clear();
   return n;
+}
+
+// ---------------------------------------------------------------------------
+// K2: Gram + eigen-decomposition
+// ---------------------------------------------------------------------------
+#include "plsr_gram.hip.h"
+
+namespace {
+struct GramPlan {
+  int MC, B, MM, ks;
+  int ngroups, nchunk, tiles_per_chunk;
+  int64_t nvt;
+  size_t lds, part_elems, bytes;
+};
+
+bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, GramPlan &g) {
+  if (n <= 0 || m <= 0 || items <= 0 || p <= 0) return false;
+  const int nk = (n + 3) / 4;
+  g.MC = (m + 15) / 16;
+  if (g.MC > 6) return false;
+  g.MM = g.MC * 16;
+  const int cand1[] = {8, 4, 2, 1}, cand2[] = {2, 1}, cand3[] = {1};
+  const int *cand = g.MC == 1 ? cand1 : (g.MC == 2 ? cand2 : cand3);
+  const int ncand = g.MC == 1 ? 4 : (g.MC == 2 ? 2 : 1);
+  g.B = 0;
+  for (int i = 0; i < ncand; ++i) {
+    if (cand[i] > 1 && cand[i] > items) continue;
+    // operator fragments may take at most 96 KiB; the rest stages rows of X
+    if ((size_t)cand[i] * g.MC * nk * 512 <= 96 * 1024) {
+      g.B = cand[i];
+      break;
+    }
+  }
+  if (g.B == 0) return false;
+  {
+    const size_t ops = (size_t)g.B * g.MC * nk * 512;
+    const int fit = (int)((160 * 1024 - ops) / 2048);
+    g.ks = std::min(nk, fit);
+    if (g.ks < 1) return false;
+  }
+  g.lds = gram_lds_bytes(nk, g.MC, g.B, g.ks);
+  g.ngroups = (items + g.B - 1) / g.B;
+  g.nvt = (p + TV - 1) / TV;
+  int want = (int)std::max<int64_t>(1, (1024 + g.ngroups - 1) / g.ngroups);
+  want = (int)std::min<int64_t>(want, g.nvt);
+  g.tiles_per_chunk = (int)((g.nvt + want - 1) / want);
+  g.nchunk = (int)((g.nvt + g.tiles_per_chunk - 1) / g.tiles_per_chunk);
+  g.part_elems = (size_t)g.nchunk * items * g.MM * g.MM;
+  g.bytes = (g.part_elems * sizeof(double) + 255) / 256 * 256;
+  return true;
+}
+
+template <int MC, int B>
+int launch_gram(const GramArgs &a, const GramPlan &g, hipStream_t st) {
+  auto kern = gram_kernel<MC, B>;
+  if (g.lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    if (e != hipSuccess) {
+      g_last_hip = (int)e;
+      return PLSR_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(g.ngroups, g.nchunk), dim3(256), g.lds, st, a);
+  return check_launch();
+}
+}  // namespace
+
+extern "C" int64_t plsr_rows_frag_elems(int32_t n, int32_t m, int32_t items) {
+  if (n <= 0 || m <= 0 || items <= 0) return 0;
+  return (int64_t)items * ((m + 15) / 16) * ((n + 3) / 4) * 64;
+}
+
+extern "C" int plsr_ops_pack_rows(const double *d_rows, int32_t items, int32_t m, int32_t n,
+                                  double *d_frag, void *stream) {
+  if (!d_rows || !d_frag || items <= 0 || m <= 0 || n <= 0) return PLSR_EINVAL;
+  const int MC = (m + 15) / 16, nk = (n + 3) / 4;
+  const int64_t total = (int64_t)items * MC * nk * 64;
+  hipLaunchKernelGGL(ops_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_rows, d_frag, items, m, n, nk, MC);
+  return check_launch();
+}
+
+extern "C" size_t plsr_gram_workspace_bytes(int32_t n, int32_t m, int32_t items, int64_t p) {
+  GramPlan g;
+  return gram_plan(n, m, items, p, g) ? g.bytes : 0;
+}
+
+extern "C" int plsr_gram_batch(const double *d_X, int64_t ldx, int64_t p, int32_t n,
+                               const double *d_frag, int32_t items, int32_t m, double *d_G,
+                               void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_frag || !d_G || !d_work || ldx < p) return PLSR_EINVAL;
+  GramPlan g;
+  if (!gram_plan(n, m, items, p, g)) return PLSR_EUNSUPPORTED;
+  if (g.bytes > work_bytes) return PLSR_EWORKSPACE;
+  GramArgs a;
+  a.X = d_X;
+  a.ldx = ldx;
+  a.p = p;
+  a.n = n;
+  a.nk = (n + 3) / 4;
+  a.frag = d_frag;
+  a.items = items;
+  a.tiles_per_chunk = g.tiles_per_chunk;
+  a.ks = g.ks;
+  a.G_part = (double *)d_work;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = PLSR_EUNSUPPORTED;
+#define PLSR_G(MCv, Bv) \
+  if (g.MC == MCv && g.B == Bv) rc = launch_gram<MCv, Bv>(a, g, st);
+  PLSR_G(1, 8) PLSR_G(1, 4) PLSR_G(1, 2) PLSR_G(1, 1) PLSR_G(2, 2) PLSR_G(2, 1)
+  PLSR_G(3, 1) PLSR_G(4, 1) PLSR_G(5, 1) PLSR_G(6, 1)
+#undef PLSR_G
+  if (rc) return rc;
+  // sum the voxel chunks (fixed order)
+  const int64_t E = (int64_t)items * g.MM * g.MM;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
+                     (const double *)d_work, d_G, E, g.nchunk, g.nchunk);
+  return check_launch();
+}
+
+extern "C" int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t ld, int32_t off,
+                               int32_t k, int32_t count, double *d_evals, double *d_evecs,
+                               void *stream) {
+  if (!d_G || !d_evals || !d_evecs || count <= 0 || k <= 0 || ld < off + k) return PLSR_EINVAL;
+  if (k > EIG_MAX) return PLSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(eigh_kernel, dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream, d_G,
+                     item_stride, ld, off, k, count, d_evals, d_evecs, 30);
+  return check_launch();
 }

@@ -1,0 +1,293 @@
+// K2: per-item cross-block Grams and their eigen-decomposition (thin SVD).
+//
+// An *item* is one decomposition request: m operator rows A (m x n) whose
+// cross-block is M = A X (m x p).  The kernel returns G = M M^T (m x m) without
+// ever storing M:
+//
+//   first product   D[v, c] = sum_i X[i, v] A[c, i]     MFMA: M = 16 voxels,
+//                                                        N = 16 rows of A, K = 4
+//   Gram            G[c1, c2] += sum_v D[v, c1] D[v, c2]
+//
+// With the f64 16x16x4 accumulator map D[row = (lane>>4)+4*reg][col = lane&15]
+// the four registers of the first product are, unchanged, both the A and the B
+// operand of the Gram MFMA for k-step `reg` (cdna guide section 3, "an
+// accumulator tile as the next MFMA's operand"), so the Gram needs no LDS
+// round trip.  For a split-half item the rows are the two halves' operators
+// stacked, and G holds M1 M1^T, M1 M2^T and M2 M2^T at once.
+//
+// Reference arithmetic replaced: class_functions.py:98-123 (_run_pls ->
+// np.linalg.svd) as used by split_half_resampling.py:194-196, :612-613,
+// :682-683 and by the PLS constructors (pls_classes.py:261).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plsr_project.hip.h"
+
+namespace plsr {
+
+struct GramArgs {
+  const double *X;
+  int64_t ldx, p;
+  int32_t n, nk;
+  const double *frag;    // [items*MC][nk][64], rows layout
+  int32_t items;
+  int32_t tiles_per_chunk;   // 64-voxel tiles per voxel chunk
+  int32_t ks;                // k-steps of X staged in LDS at a time (rows of X are K-chunked)
+  double *G_part;        // [nchunk][items][mm][mm]
+};
+
+// MC = 16-row tiles per item, B = items per workgroup
+template <int MC, int B>
+__global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NG = MC * (MC + 1) / 2;
+  constexpr int MM = MC * 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int nrows = A.nk * 4;
+  const int item0 = blockIdx.x * B;
+  const int chunk = blockIdx.y;
+
+  double *ops = smem;                                   // [B][MC][nk][64]
+  double *Xs = smem + (size_t)B * MC * A.nk * 64;       // [4*ks][64]
+
+  // operator fragments of this workgroup's items -> LDS (once)
+  {
+    const int64_t total = (int64_t)B * MC * A.nk * 64;
+    for (int64_t e = tid; e < total; e += 256) {
+      const int b = (int)(e / ((int64_t)MC * A.nk * 64));
+      const int item = item0 + b;
+      ops[e] = item < A.items ? A.frag[(int64_t)item0 * MC * A.nk * 64 + e] : 0.0;
+    }
+  }
+
+  f64x4 G[B][NG];
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) G[b][i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t nvt = (A.p + TV - 1) / TV;
+  const int64_t t_lo = (int64_t)chunk * A.tiles_per_chunk;
+  const int64_t t_hi = min(nvt, t_lo + A.tiles_per_chunk);
+  const int xo = xs_index(g, wave * 16 + col);          // A operand: voxel = col of this wave's 16, row = g
+
+  for (int64_t vt = t_lo; vt < t_hi; ++vt) {
+    const int64_t v0 = vt * TV;
+    f64x4 D[B][MC];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) D[b][mc] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int ks0 = 0; ks0 < A.nk; ks0 += A.ks) {
+      const int ks1 = min(A.nk, ks0 + A.ks);
+      __syncthreads();                                  // previous X chunk fully consumed (and ops written)
+      for (int r0 = 4 * ks0; r0 < 4 * ks1; r0 += 16) {
+        double tmp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = r0 + u * 4 + (tid >> 6);
+          const int64_t v = v0 + lane;
+          tmp[u] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = r0 + u * 4 + (tid >> 6);
+          if (row < 4 * ks1) Xs[xs_index(row - 4 * ks0, lane)] = tmp[u];
+        }
+      }
+      __syncthreads();
+      for (int s = ks0; s < ks1; ++s) {
+        const double a = Xs[(size_t)(s - ks0) * 4 * TV + xo];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc)
+            D[b][mc] = mfma_f64(a, ops[((size_t)(b * MC + mc) * A.nk + s) * 64 + lane], D[b][mc]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      int idx = 0;
+#pragma unroll
+      for (int m1 = 0; m1 < MC; ++m1)
+#pragma unroll
+        for (int m2 = m1; m2 < MC; ++m2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) G[b][idx] = mfma_f64(D[b][m1][r], D[b][m2][r], G[b][idx]);
+          ++idx;
+        }
+    }
+  }
+
+  // ---- sum the four waves' Gram tiles through LDS and write the slab ----
+  __syncthreads();
+  double *red = smem;                                   // [B][NG][4][64], waves add in turn
+  for (int w = 0; w < WAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double *dst = red + (((size_t)b * NG + i) * 4 + r) * 64 + lane;
+            *dst = (w == 0 ? 0.0 : *dst) + G[b][i][r];
+          }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < B * MM * MM; e += 256) {
+    const int b = e / (MM * MM);
+    const int c1 = (e / MM) % MM;
+    const int c2 = e % MM;
+    const int item = item0 + b;
+    if (item >= A.items) continue;
+    // upper-triangle tile (m1 <= m2) holds G[c1][c2] for c1 in tile m1, c2 in tile m2
+    int lo = c1, hi = c2;
+    if ((c1 >> 4) > (c2 >> 4)) { lo = c2; hi = c1; }
+    const int m1 = lo >> 4, m2 = hi >> 4;
+    const int idx = m1 * MC - m1 * (m1 - 1) / 2 + (m2 - m1);
+    const int rr = lo & 15, cc = hi & 15;               // row = (lane>>4) + 4*reg, col = lane&15
+    const int src_lane = ((rr & 3) << 4) | cc;
+    const int reg = rr >> 2;
+    A.G_part[(((int64_t)chunk * A.items + item) * MM + c1) * MM + c2] =
+        red[(((size_t)b * NG + idx) * 4 + reg) * 64 + src_lane];
+  }
+}
+
+inline size_t gram_lds_bytes(int nk, int mc, int b, int ks) {
+  size_t a = ((size_t)b * mc * nk * 64 + (size_t)ks * 4 * TV) * sizeof(double);
+  size_t r = (size_t)b * (mc * (mc + 1) / 2) * 4 * 64 * sizeof(double);
+  return a > r ? a : r;
+}
+
+// rows layout: tile t = item*MC + mc, lane (m = lane&15, kk = lane>>4) holds
+// rows[item][16*mc + m][4*s + kk]
+__global__ __launch_bounds__(256) void ops_rows_kernel(const double *rows, double *frag, int items,
+                                                       int m, int n, int nk, int MC) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)items * MC * nk * 64;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  const int s = (int)((e >> 6) % nk);
+  const int64_t t = (e >> 6) / nk;
+  const int item = (int)(t / MC);
+  const int j = (int)(t % MC) * 16 + (lane & 15);
+  const int i = 4 * s + (lane >> 4);
+  frag[e] = (j < m && i < n) ? rows[((int64_t)item * m + j) * n + i] : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// batched symmetric eigen-decomposition: one wavefront per matrix, cyclic
+// two-sided Jacobi with a round-robin (tournament) ordering in LDS.
+// Eigenvalues come back in descending order with matching eigenvector columns.
+// ---------------------------------------------------------------------------
+constexpr int EIG_MAX = 64;
+
+__global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t item_stride, int ld,
+                                                  int off, int k, int count, double *evals,
+                                                  double *evecs, int max_sweeps) {
+  __shared__ double As[EIG_MAX * (EIG_MAX + 1)];
+  __shared__ double Vs[EIG_MAX * (EIG_MAX + 1)];
+  __shared__ double cs[EIG_MAX], sn[EIG_MAX];
+  __shared__ int pp[EIG_MAX], qq[EIG_MAX];
+  const int item = blockIdx.x;
+  if (item >= count) return;
+  const int lane = threadIdx.x;
+  const int LD = EIG_MAX + 1;
+  const double *G = Gsrc + (int64_t)item * item_stride + (int64_t)off * ld + off;
+  const int kk = (k + 1) & ~1;            // players in the tournament (one dummy if k is odd)
+  for (int e = lane; e < k * k; e += 64) {
+    const int r = e / k, c = e % k;
+    // symmetrise: the Gram is symmetric up to rounding of two summation orders
+    As[r * LD + c] = 0.5 * (G[(int64_t)r * ld + c] + G[(int64_t)c * ld + r]);
+    Vs[r * LD + c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    // convergence: largest |a_pq| / sqrt(a_pp a_qq)
+    double worst = 0.0;
+    for (int e = lane; e < k * k; e += 64) {
+      const int r = e / k, c = e % k;
+      if (r < c) {
+        const double d = sqrt(fabs(As[r * LD + r] * As[c * LD + c]));
+        const double o = fabs(As[r * LD + c]);
+        const double rel = d > 0.0 ? o / d : (o > 0.0 ? 1.0 : 0.0);
+        worst = fmax(worst, rel);
+      }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) worst = fmax(worst, __shfl_xor(worst, sft));
+    if (worst < 1e-15) break;
+    for (int step = 0; step < kk - 1; ++step) {
+      // round-robin pairing: player 0 fixed, the others rotate
+      if (lane < kk / 2) {
+        int a = lane == 0 ? 0 : 1 + (lane - 1 + step) % (kk - 1);
+        int b = 1 + (kk - 2 - lane + step) % (kk - 1);
+        int p = min(a, b), q = max(a, b);
+        double c = 1.0, s = 0.0;
+        if (q < k) {
+          const double apq = As[p * LD + q];
+          const double app = As[p * LD + p], aqq = As[q * LD + q];
+          if (fabs(apq) > 1e-300 && fabs(apq) >= 1e-18 * sqrt(fabs(app * aqq))) {
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = t * c;
+          }
+        } else {
+          q = p;                       // dummy opponent: identity
+        }
+        pp[lane] = p;
+        qq[lane] = q;
+        cs[lane] = c;
+        sn[lane] = s;
+      }
+      __syncthreads();
+      // columns: A <- A J, V <- V J   (lane = row)
+      if (lane < k) {
+        for (int i = 0; i < kk / 2; ++i) {
+          const int p = pp[i], q = qq[i];
+          if (p == q) continue;
+          const double c = cs[i], s = sn[i];
+          const double ap = As[lane * LD + p], aq = As[lane * LD + q];
+          As[lane * LD + p] = c * ap - s * aq;
+          As[lane * LD + q] = s * ap + c * aq;
+          const double vp = Vs[lane * LD + p], vq = Vs[lane * LD + q];
+          Vs[lane * LD + p] = c * vp - s * vq;
+          Vs[lane * LD + q] = s * vp + c * vq;
+        }
+      }
+      __syncthreads();
+      // rows: A <- J^T A   (lane = column)
+      if (lane < k) {
+        for (int i = 0; i < kk / 2; ++i) {
+          const int p = pp[i], q = qq[i];
+          if (p == q) continue;
+          const double c = cs[i], s = sn[i];
+          const double ap = As[p * LD + lane], aq = As[q * LD + lane];
+          As[p * LD + lane] = c * ap - s * aq;
+          As[q * LD + lane] = s * ap + c * aq;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // sort descending (rank by counting) and write out
+  double lam = lane < k ? As[lane * LD + lane] : 0.0;
+  int rank = 0;
+  if (lane < k) {
+    for (int j = 0; j < k; ++j) {
+      const double lj = As[j * LD + j];
+      rank += (lj > lam) || (lj == lam && j < lane);
+    }
+    evals[(int64_t)item * k + rank] = lam;
+    for (int r = 0; r < k; ++r) evecs[((int64_t)item * k + r) * k + rank] = Vs[r * LD + lane];
+  }
+}
+
+}  // namespace plsr

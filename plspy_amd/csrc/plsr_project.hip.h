@@ -22,13 +22,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PLSR_ABLATE
+#define PLSR_ABLATE 0   // developer-only timing ablations (wrong results when non-zero)
+#endif
+
 namespace plsr {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TV = 64;         // voxels per workgroup
 constexpr int NT = TV / 16;    // MFMA N-tiles per workgroup
-constexpr int DT_LD = 66;      // padded row of the per-wave transpose patch
+constexpr int DT_LD = 18;      // padded row of the per-wave 16 x 16 transpose patch
 constexpr int WAVES = 4;
 constexpr int MAX_PERIOD = 6;
 
@@ -46,7 +50,7 @@ struct ProjectArgs {
   const double *Xm;     // [k2][ldxm] or null
   int64_t ldxm;
   int32_t k2;
-  double *S1, *S2;      // [p][k], accumulated
+  double *S1, *S2;      // [column split][p][k] partial moment sums (overwritten)
   double *vs_dump;      // [R][p][k] or null
 };
 
@@ -126,39 +130,96 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
   __syncthreads();
 
   const int64_t C = (int64_t)A.ntiles * 16;
+  const int nk = A.nk;
+  // blockIdx.y splits the batch tiles (in whole wave x period groups) so that the
+  // grid quantises well on 256 CUs; each split owns its own moment partials.
+  const int cs = blockIdx.y;
+  const int group = WAVES * PERIOD;
+  const int gps = ((A.ntiles + group - 1) / group + gridDim.y - 1) / gridDim.y;
+  const int t_begin = cs * gps * group;
+  const int t_end = min(A.ntiles, t_begin + gps * group);
+  const int rem = nk & 3;
 
-  for (int base = wave * PERIOD; base < A.ntiles; base += WAVES * PERIOD) {
+  // Software pipeline of the main contraction.  `ring` holds this wave's
+  // operator fragments (MFMA A operand) four k-steps ahead of use -- across
+  // tile boundaries too: during a tile's last four k-steps the ring is refilled
+  // from the wave's NEXT tile, so the L2 latency of a fragment load is covered
+  // by 16 MFMAs.  `bn` holds the X fragments (B operand, from LDS) one k-step
+  // ahead.  The loop body has no branches, so MFMAs issue back to back.
+  double ring[4];
+  double bn[NT];
+  {
+    const int tf = t_begin + wave * PERIOD;
+    const double *ap0 = A.frag + ((size_t)(tf < t_end ? tf : 0) * nk) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ring[u] = ap0[(u < nk ? u : nk - 1) * 64];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bn[nt] = Xs[xo[nt]];
+  }
+
+  for (int base = t_begin + wave * PERIOD; base < t_end; base += WAVES * PERIOD) {
 #pragma unroll
     for (int sl = 0; sl < PERIOD; ++sl) {
       const int t = base + sl;
-      if (t >= A.ntiles) break;
+      if (t >= t_end) break;
 
       // ---------------- main contraction ----------------
       f64x4 acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-      const double *ap = A.frag + ((size_t)t * A.nk) * 64 + lane;
-      double an[4];
+      const double *ap = A.frag + ((size_t)t * nk) * 64 + lane;
+      // this wave's next tile (or this one again at the very end: any valid address)
+      int tn = (sl + 1 < PERIOD && t + 1 < t_end) ? t + 1 : base + WAVES * PERIOD;
+      if (tn >= t_end) tn = t;
+      const double *apn = A.frag + ((size_t)tn * nk) * 64 + lane;
+
+      auto step = [&](int s, double a) {
+        double b[NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) an[u] = (u < A.nk) ? ap[u * 64] : 0.0;
-      for (int s0 = 0; s0 < A.nk; s0 += 4) {
-        double ac[4];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        const int s1 = (s + 1 == nk) ? 0 : s + 1;            // same X tile for every batch tile
+        const double *xr = Xs + (size_t)s1 * 4 * TV;
+#if !(PLSR_ABLATE & 4)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ac[u] = an[u];
-        const int s1n = s0 + 4;
-        if (s1n < A.nk) {
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = xr[xo[nt]];
+#endif
 #pragma unroll
-          for (int u = 0; u < 4; ++u) an[u] = (s1n + u < A.nk) ? ap[(s1n + u) * 64] : 0.0;
-        }
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(a, b[nt], acc[nt]);
+      };
+      auto fetch = [&](int s) -> double {                    // fragment of absolute k-step s (may run into the next tile)
+        const int sc = s < nk ? s : (s - nk < nk ? s - nk : nk - 1);
+#if PLSR_ABLATE & 2
+        return 1.0 + sc;
+#else
+        return (s < nk ? ap : apn)[(size_t)sc * 64];
+#endif
+      };
+
+      if (nk >= 4) {
+        int s = 0;
+        for (; s + 4 <= nk; s += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (s0 + u < A.nk) {
-            const double *xr = Xs + (size_t)(s0 + u) * 4 * TV;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(ac[u], xr[xo[nt]], acc[nt]);
+          for (int u = 0; u < 4; ++u) {
+            const double a = ring[u];
+            ring[u] = fetch(s + u + 4);
+            step(s + u, a);
           }
         }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (u < rem) {
+            const double a = ring[u];
+            ring[u] = fetch(s + u + 4);
+            step(s + u, a);
+          }
+        }
+        // the ring now starts `rem` slots in: rotate it back so slot u = next tile's k-step u
+        if (rem == 1) { const double x = ring[0]; ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3]; ring[3] = x; }
+        if (rem == 2) { double x = ring[0]; ring[0] = ring[2]; ring[2] = x; x = ring[1]; ring[1] = ring[3]; ring[3] = x; }
+        if (rem == 3) { const double x = ring[3]; ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = x; }
+      } else {
+        for (int s = 0; s < nk; ++s) step(s, ap[(size_t)s * 64]);   // tiny n: not pipelined
       }
 
       // quad / resample bookkeeping of this lane group
@@ -204,22 +265,31 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
         }
       }
 
+#if PLSR_ABLATE & 1
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(acc[nt]));
+      continue;
+#endif
       // ---------------- voxel contractions via the transpose patch ----------------
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Dt[(g + 4 * r) * DT_LD + nt * 16 + col] = acc[nt][r];
-      }
-      __builtin_amdgcn_wave_barrier();
+      // one 16-voxel block at a time through a 16 x 18 (padded) per-wave patch:
+      // written in accumulator layout, read back as A[m = col][k = g]
       double nsq = 0.0;
       f64x4 accT = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const double av = Dt[col * DT_LD + 4 * s + g];
-        nsq = fma(av, av, nsq);
-        if (BOOT) accT = mfma_f64(av, xm[s], accT);
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dt[(g + 4 * r) * DT_LD + col] = acc[nt][r];
+        __builtin_amdgcn_wave_barrier();
+        double av[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[s] = Dt[col * DT_LD + 4 * s + g];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          nsq = fma(av[s], av[s], nsq);
+          if (BOOT) accT = mfma_f64(av[s], xm[4 * nt + s], accT);
+        }
       }
-      __builtin_amdgcn_wave_barrier();
       nsq += __shfl_xor(nsq, 16);
       nsq += __shfl_xor(nsq, 32);
       if (g == 0) A.norm_part[vt * C + (int64_t)t * 16 + col] = nsq;
@@ -246,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
           red[((wave * PERIOD + sl) * 4 + g) * TV + nt * 16 + col] = pass == 0 ? s1[sl][nt] : s2[sl][nt];
       }
       __syncthreads();
-      double *out = pass == 0 ? A.S1 : A.S2;
+      double *out = (pass == 0 ? A.S1 : A.S2) + (int64_t)cs * A.p * A.k;
       for (int e = tid; e < TV * A.k; e += 256) {
         const int vl = e / A.k;
         const int j = e % A.k;
@@ -257,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
           for (int qq = j; qq < 4 * PERIOD; qq += A.kp)
             sum += red[((w * PERIOD + (qq >> 2)) * 4 + (qq & 3)) * TV + vl];
         }
-        out[v * A.k + j] += sum;
+        out[v * A.k + j] = sum;
       }
     }
   }
@@ -346,6 +416,16 @@ __global__ __launch_bounds__(256) void slab_final_kernel(const double *in, doubl
   double a = 0.0;
   for (int s = 0; s < nslab; ++s) a += in[(int64_t)s * C * w + e];
   out[(b * k + j) * w + cc] = a;
+}
+
+// S[e] += sum over column splits of part[c][e]  (fixed order)
+__global__ __launch_bounds__(256) void moment_merge_kernel(double *S, const double *part, int64_t count,
+                                                           int nsplit) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  double a = part[e];
+  for (int c = 1; c < nsplit; ++c) a += part[(int64_t)c * count + e];
+  S[e] += a;
 }
 
 // std / bootstrap-ratio from shifted moments

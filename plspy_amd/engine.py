@@ -157,3 +157,61 @@ class ProjectionEngine:
             res = self.boot_phase(blk.shape[0], cols=blk[None, :, :], dump=True)
             out.append(res["vs"][0].T)
         return torch.cat(out, dim=0)
+
+    # -- K2: Gram / thin SVD -------------------------------------------------
+    def gram_phase(self, rows):
+        """rows: (S, m, n) operator rows (NumPy).  Returns the (S, mm, mm) Grams
+        (A_s X)(A_s X)^T on the device, mm = 16*ceil(m/16)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        S, m, n = rows.shape
+        assert n == self.n
+        mm = (m + 15) // 16 * 16
+        G = torch.empty((S, mm, mm), dtype=torch.float64, device=self.device)
+        per_item = self.lib.plsr_rows_frag_elems(n, m, 1) * 8 + m * n * 8
+        step = max(1, min(S, self.work_limit // max(per_item, 1)))
+        for lo in range(0, S, step):
+            hi = min(S, lo + step)
+            cnt = hi - lo
+            d_rows = self.dev(rows[lo:hi])
+            frag = torch.empty(self.lib.plsr_rows_frag_elems(n, m, cnt), dtype=torch.float64,
+                               device=self.device)
+            _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_rows), cnt, m, n, _ptr(frag), _stream()),
+                       "plsr_ops_pack_rows")
+            need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p)
+            if need == 0:
+                raise _lib.PlsrError(f"plsr_gram: unsupported shape n={n} m={m}")
+            work = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.plsr_gram_batch(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(frag),
+                                                cnt, m, _ptr(G[lo:hi]), _ptr(work), need, _stream()),
+                       "plsr_gram_batch")
+        return G
+
+    def eigh(self, G, off, k):
+        """Eigen-decomposition of the k x k diagonal block at `off` of every
+        matrix in G (S, mm, mm): (evals (S,k) descending, evecs (S,k,k))."""
+        S, mm, _ = G.shape
+        ev = torch.empty((S, k), dtype=torch.float64, device=self.device)
+        vec = torch.empty((S, k, k), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.plsr_eigh_batch(_ptr(G), mm * mm, mm, off, k, S, _ptr(ev), _ptr(vec),
+                                            _stream()), "plsr_eigh_batch")
+        return ev, vec
+
+    def thin_svd(self, rows, null_tol=None):
+        """Thin SVD of M = rows @ X (k x p) without forming M on the host:
+        Gram -> Jacobi -> back-projection V = M^T U / s through the projection
+        kernel.  Singular values below sqrt(null_tol)*s_max are deflated to 0
+        (their vectors are returned as 0); see DESIGN.md (null latent variables)."""
+        rows = np.asarray(rows, dtype=float)
+        k = rows.shape[0]
+        G = self.gram_phase(rows[None])
+        ev, vec = self.eigh(G, 0, k)
+        lam = ev[0].cpu().numpy()
+        U = vec[0].cpu().numpy()
+        tol = (64 * k * np.finfo(float).eps) if null_tol is None else null_tol
+        live = lam > tol * max(lam[0], 0.0)
+        s = np.sqrt(np.where(live, lam, 0.0))
+        cols = (rows.T @ U).T                           # k operator columns: VS = X^T (A^T U)
+        VS = self.boot_phase(k, cols=cols[None], dump=True)["vs"][0].cpu().numpy()   # p x k
+        with np.errstate(divide="ignore", invalid="ignore"):
+            V = np.where(live[None, :], VS / s[None, :], 0.0)
+        return U, s, V

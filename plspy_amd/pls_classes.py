@@ -129,15 +129,15 @@ class _MeanCentreTaskPLS(PLSBase):
 
         engine = ProjectionEngine(X)
         co = np.asarray(self.cond_order)
-        # observed decomposition (pls_classes.py:258-266); the two k x p blocks
-        # come from the projection kernel, the k x p thin SVD is LAPACK as in
-        # the reference (class_functions.py:122)
+        # observed decomposition (pls_classes.py:258-266), on the device: the
+        # two k x p blocks come from the projection kernel, the thin SVD
+        # (class_functions.py:122) from the Gram + Jacobi + back-projection
+        # kernels (engine.thin_svd)
         Wm = operators.cell_mean_operator(co)
         W = operators.mean_centre_operator(co, self.mctype)
         blocks = engine.apply_operator(np.vstack((Wm, W))).cpu().numpy()
         self.X_means, self.X_mc = blocks[:len(Wm)], blocks[len(Wm):]
-        U, self.s, Vt = np.linalg.svd(self.X_mc, full_matrices=False)
-        self.U, self.V = U, Vt.T
+        self.U, self.s, self.V = engine.thin_svd(W)
         self.X_latent = np.dot(self.X, self.V)
         Tvsc_orig = Wm @ self.X_latent
 
