@@ -138,9 +138,12 @@ int64_t plsr_rows_frag_elems(int32_t n, int32_t m, int32_t items);
 /* d_rows[item][j][i] (items x m x n fp64) -> MFMA operand fragments */
 int plsr_ops_pack_rows(const double *d_rows, int32_t items, int32_t m, int32_t n,
                        double *d_frag, void *stream);
-size_t plsr_gram_workspace_bytes(int32_t n, int32_t m, int32_t items, int64_t p);
-/* d_G[item][mm][mm], mm = 16*ceil(m/16); rows/cols >= m are zero */
-int plsr_gram_batch(const double *d_X, int64_t ldx, int64_t p, int32_t n,
+size_t plsr_gram_workspace_bytes(int32_t n, int32_t m, int32_t items, int64_t p,
+                                 int64_t x_item_stride);
+/* d_G[item][mm][mm], mm = 16*ceil(m/16); rows/cols >= m are zero.
+ * x_item_stride = 0: all items contract the same X; otherwise item i uses the
+ * n x ldx matrix at d_X + i*x_item_stride (per-item z-scored data, K3). */
+int plsr_gram_batch(const double *d_X, int64_t x_item_stride, int64_t ldx, int64_t p, int32_t n,
                     const double *d_frag, int32_t items, int32_t m, double *d_G,
                     void *d_work, size_t work_bytes, void *stream);
 /*
@@ -152,6 +155,21 @@ int plsr_gram_batch(const double *d_X, int64_t ldx, int64_t p, int32_t n,
  */
 int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t ld, int32_t off,
                     int32_t k, int32_t count, double *d_evals, double *d_evecs, void *stream);
+
+/*
+ * ---- K3: row gather + per-cell z-score --------------------------------------
+ * The data side of _compute_corr (class_functions.py:185-247): for every item,
+ *   out[item][r][:] = X[src[item][r]][:]                         for rows of raw cells
+ *   out[item][r][:] = zscore over the cell's rows (ddof 0) / sqrt(n_cell)   for z cells
+ * cells are the output-row ranges [cell_lo[c], cell_lo[c+1]).  Voxels that are
+ * constant within a cell give 0 there (scipy's zscore rule + nan_to_num).
+ * Contracting the result with z-scored behaviour columns gives R = Yz.T @ Xz.
+ *   d_src : [items][nout] int32     d_out : [items][nout][ldo] fp64
+ */
+int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, const int32_t *d_src,
+                       int32_t items, int32_t nout, const int32_t *d_cell_lo,
+                       const int32_t *d_cell_z, int32_t ncell, double *d_out, int64_t ldo,
+                       void *stream);
 
 /*
  * Kernel timing for the roofline report (bench.py).  When enabled, every

@@ -38,8 +38,9 @@ SIGNATURES = {
     "plsr_boot_finalize": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "plsr_rows_frag_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "plsr_ops_pack_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "plsr_gram_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
-    "plsr_gram_batch": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_gram_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64, c_i64]),
+    "plsr_gram_batch": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_gather_zscore": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "plsr_eigh_batch": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "plsr_timing_enable": (c_i32, [c_i32]),
     "plsr_timing_collect": (c_i32, [c_vp, c_vp, c_i32]),

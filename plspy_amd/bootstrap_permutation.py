@@ -7,21 +7,28 @@ the reference's signature and returns an object with the same attributes
 boot_ratios, boot_debug_dict, ...).  What differs is how the numbers are made:
 
 * no row gather of X and no per-iteration preprocess: resample, preprocess and
-  projection onto the observed U are folded into one (n x k) operator per
-  resample (operators.py) which the HIP kernels
-  contract with the HBM-resident X, a whole phase per launch;
+  projection onto the observed U are folded into one operator per resample
+  (operators.py) which the HIP kernels contract with
+  an HBM-resident matrix, a whole phase per launch.  For task PLS that matrix
+  is X; for behaviour PLS it is X z-scored within cells (the permutation only
+  moves Y, quirk Q15); for multiblock PLS it is [X; z-scored bscan rows];
 * the bootstrap never materialises right_sv_sampled (R x p x k): moments are
   streamed in-kernel and std_errs / boot_ratios are formed once at the end;
 * with torch.distributed initialised, resample ids are sharded over the ranks
   and merged with one collective per phase (dist.py).
 
-Random draws replicate the reference's np.random call order (resample.py)."""
+Random draws replicate the reference's np.random call order (resample.py).
+
+Round-1 coverage: permutation test for mct, rb, mb; bootstrap test for mct.
+The rb / mb bootstrap (per-resample z-scoring of resampled rows) raises
+NotImplementedError -- it does not fall back to a CPU path."""
 import abc
 
 import numpy as np
 import torch
 from scipy.stats import norm
 
+from . import class_functions as cf
 from . import dist, exceptions, operators, resample
 from .engine import ProjectionEngine
 
@@ -69,7 +76,13 @@ def _stepdown_totals(sv):
     return tot if np.ndim(sv) > 1 else tot[0]
 
 
+_DEGENERATE = ("Please check your behaviour data, and make sure that none of the "
+               "columns are all the same for each group.")
+
+
 @ResampleTest._register_subclass("mct")
+@ResampleTest._register_subclass("rb")
+@ResampleTest._register_subclass("mb")
 class _ResampleTestPLS(ResampleTest):
     def __init__(self, X, Y, U, s, V, cond_order, mctype, contrast=None, preprocess=None,
                  nperm=1000, nboot=1000, bscan=None, Xbscan=None, Ybscan=None,
@@ -82,25 +95,28 @@ class _ResampleTestPLS(ResampleTest):
         self._cond_order = np.asarray(cond_order)
         self._mctype = mctype
         self._engine = engine if engine is not None else ProjectionEngine(X)
-        self._X = X
+        self._X, self._Y = X, Y
+        self._bscan, self._Ybscan = bscan, Ybscan
         n = self._engine.n
-        if self.pls_alg == "mct":
-            if preprocess is not None:
-                W = operators.operator_from_callable(preprocess, n, self._cond_order, mctype)
+        if self.pls_alg in ("mct", "mb"):
+            if preprocess is not None and self.pls_alg == "mct":
+                # a linear preprocess with the reference's signature: its operator
+                # is its action on the identity
+                self._W = operators.operator_from_callable(preprocess, n, self._cond_order, mctype)
             else:
-                W = operators.mean_centre_operator(self._cond_order, mctype)
-            self._W = W
-        else:
-            raise exceptions.NotImplementedError(
-                f"{self._pls_types.get(self.pls_alg, self.pls_alg)} resampling is not available yet")
+                self._W = operators.mean_centre_operator(self._cond_order, mctype)
 
         if nperm > 0:
-            self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = self._permutation_test(
-                U, s, nperm)
+            perm = {"mct": self._perm_mct, "rb": self._perm_rb, "mb": self._perm_mb}[self.pls_alg]
+            self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = perm(U, s, nperm)
         else:                                   # bootstrap_permutation.py:181-182
             self.permute_ratio = "NA"
             self.stepdown_ratio = "NA"
         if nboot > 0:
+            if self.pls_alg != "mct":
+                raise exceptions.NotImplementedError(
+                    f"the {self._pls_types[self.pls_alg]} bootstrap is not available on the GPU "
+                    "engine yet (pass num_boot=0); there is no CPU fallback")
             (self.conf_ints, self.std_errs, self.boot_ratios,
              self.boot_debug_dict) = self._bootstrap_test(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
         else:                                   # :261-263
@@ -109,22 +125,44 @@ class _ResampleTestPLS(ResampleTest):
             self.boot_ratios = "NA"
 
     # ------------------------------------------------------------------
-    def _permutation_test(self, U, s, niter, threshold=1e-12):
+    # shared pieces
+    # ------------------------------------------------------------------
+    @staticmethod
+    def _run_perm(eng, k, niter, inds=None, M=None, cols=None):
+        """Shard the phase's resamples, run the permutation kernel, gather."""
+        rank, nranks = dist.world()
+        lo, hi = dist.shard_bounds(niter, rank, nranks)
+        if cols is not None:
+            ssq = eng.perm_phase(k, cols=cols[lo:hi])
+        else:
+            ssq = eng.perm_phase(k, inds=inds[lo:hi], M=M)
+        (ssq,), _ = dist.exchange([ssq], [], niter)
+        return ssq.cpu().numpy()
+
+    @staticmethod
+    def _ratios(s_hat, s_ref, step_ref, niter):
+        greatersum = np.sum(s_hat >= s_ref, axis=0).astype(float)                 # :427/:437
+        step = np.sum(_stepdown_totals(s_hat) >= _stepdown_totals(step_ref), axis=0).astype(float)
+        return greatersum / (niter + 1), step / (niter + 1)                       # :444, :452 (Q2)
+
+    def _draw_on_rank0(self, fn):
+        rank, _ = dist.world()
+        out = fn() if rank == 0 else None
+        return dist.broadcast_indices(out, self._engine.device)
+
+    # ------------------------------------------------------------------
+    # permutation tests
+    # ------------------------------------------------------------------
+    def _perm_mct(self, U, s, niter, threshold=1e-12):
         """bootstrap_permutation.py:266-464 for mct."""
         eng = self._engine
         k = U.shape[1]
         s[np.abs(s) < threshold] = 0            # in place, like the reference (:295, quirk Q1)
-        rank, nranks = dist.world()
-        inds = resample.task_permutations(self._cond_order, niter) if rank == 0 else None
-        inds = dist.broadcast_indices(inds, eng.device)
-        lo, hi = dist.shard_bounds(niter, rank, nranks)
+        inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
         M = self._W.T @ np.asarray(U, dtype=float)      # n x k:  VS = X^T (P^T W^T U)
-        ssq = eng.perm_phase(k, inds=inds[lo:hi], M=M)
-        (ssq,), _ = dist.exchange([ssq], [], niter)
-        s_hat = np.sqrt(ssq.cpu().numpy())
+        s_hat = np.sqrt(self._run_perm(eng, k, niter, inds=inds, M=M))
         s_hat[np.abs(s_hat) < threshold] = 0    # :436
-        greatersum = np.sum(s_hat >= s, axis=0).astype(float)          # :437
-        step = np.sum(_stepdown_totals(s_hat) >= _stepdown_totals(np.copy(s)), axis=0).astype(float)
+        ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
         total = np.sum(s_hat ** 2, axis=1)
         debug = {
             "s_list": s_hat,
@@ -134,8 +172,118 @@ class _ResampleTestPLS(ResampleTest):
             "sum_perm": total.copy(),
             "indices": inds,
         }
-        return greatersum / (niter + 1), step / (niter + 1), debug     # :444, :452 (Q2)
+        return ratio, step, debug
 
+    def _draw_behaviour_perms(self, Ysrc, niter, with_task):
+        """Row permutations of the behaviour block (and, for multiblock, the task
+        permutation drawn just before each), redrawn up to 100 times while any
+        group std of the permuted Y is 0 (:333-355; the guard uses the full
+        cond_order even on the bscan subset, quirk Q8)."""
+        co = self._cond_order
+        rows = np.empty((niter, Ysrc.shape[0]), dtype=np.int32)
+        task = np.empty((niter, int(co.sum())), dtype=np.int32) if with_task else None
+        table = np.concatenate(resample.subject_tables(co)) if with_task else None
+        for i in range(niter):
+            for _ in range(100):
+                if with_task:
+                    task[i] = resample.draw_task_permutation(table)           # :343
+                rows[i] = np.random.permutation(Ysrc.shape[0])                # :338 / :347
+                if not (cf.group_stds(Ysrc[rows[i]], co) == 0).any():
+                    break
+            else:
+                raise Exception(_DEGENERATE)                                   # :355
+        return (np.concatenate((task, rows), axis=1) if with_task else rows)
+
+    def _perm_rb(self, U, s, niter, threshold=1e-12):
+        """:266-464 for rb.  Only Y is permuted; X enters through its per-cell
+        z-scores, computed once on the device (the reference recomputes them in
+        every iteration, quirk Q15)."""
+        eng = self._engine
+        co = self._cond_order
+        Y = np.asarray(self._Y, dtype=float)
+        U = np.asarray(U, dtype=float)
+        n, b = Y.shape
+        k = U.shape[1]
+        bounds = cf.cell_bounds(co)
+        s[np.abs(s) < threshold] = 0
+        perms = self._draw_on_rank0(lambda: self._draw_behaviour_perms(Y, niter, False))
+        Xz = eng.gather_zscore(np.arange(n), bounds, np.ones(len(bounds) - 1))[0]
+        eng_z = ProjectionEngine(Xz, device=eng.device, work_limit=eng.work_limit)
+        # operator column (b, j)[i] = sum_beh Yz_b[i, beh] * U[(cell(i), beh), j]
+        Yz = cf.zscore_cells(Y[perms], bounds)                                 # R x n x b
+        cols = np.empty((niter, k, n))
+        for c, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            cols[:, :, lo:hi] = np.einsum("rib,bj->rji", Yz[:, lo:hi], U[c * b:(c + 1) * b])
+        s_hat = np.sqrt(self._run_perm(eng_z, k, niter, cols=cols))
+        s_hat[np.abs(s_hat) < threshold] = 0
+        ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
+        total = np.sum(s_hat ** 2, axis=1)
+        debug = {"s_list": s_hat, "sum_s": total, "sum_perm": total.copy(), "indices": perms}
+        return ratio, step, debug
+
+    def _perm_mb(self, U, s, niter, threshold=1e-12):
+        """:266-464 for mb.  The multiblock rows are linear in the stacked matrix
+        [X; z-scored bscan rows of X]; the per-row normalisation over all voxels
+        (class_functions.py:503-505) is folded into the projection as
+        raw.T @ (D^-1 U) after a first pass that returns the row norms D
+        (SURVEY.md appendix A6)."""
+        eng = self._engine
+        co = self._cond_order
+        bscan = list(self._bscan)
+        Yb = np.asarray(self._Ybscan, dtype=float)
+        U = np.asarray(U, dtype=float)
+        ng, nc = co.shape
+        n = int(co.sum())
+        nb, b = Yb.shape
+        k = U.shape[1]
+        nbs = len(bscan)
+        per = nc + nbs * b                                   # rows per group in the stacked block
+        s[np.abs(s) < threshold] = 0
+        mask = cf.bscan_mask(co, bscan)
+        bounds_b = cf.cell_bounds(co[:, bscan])
+        Xzb = eng.gather_zscore(np.flatnonzero(mask), bounds_b, np.ones(len(bounds_b) - 1))[0]
+        eng_c = ProjectionEngine(torch.cat((eng.X, Xzb), dim=0), device=eng.device,
+                                 work_limit=eng.work_limit)
+
+        def raw_rows(task_rows, Yz):
+            """k x (n + nb) operators of the un-normalised multiblock rows for a
+            batch: task_rows (R, g*c, n), Yz (R, nb, b) z-scored behaviour."""
+            R = task_rows.shape[0]
+            A = np.zeros((R, k, n + nb))
+            for g in range(ng):
+                A[:, g * per:g * per + nc, :n] = task_rows[:, g * nc:(g + 1) * nc]
+                for ci in range(nbs):
+                    lo, hi = bounds_b[g * nbs + ci], bounds_b[g * nbs + ci + 1]
+                    r0 = g * per + nc + ci * b
+                    A[:, r0:r0 + b, n + lo:n + hi] = np.transpose(Yz[:, lo:hi], (0, 2, 1))
+            return A
+
+        # observed un-normalised block: total variance and the rescaled s (:305-312)
+        A0 = raw_rows(self._W[None], cf.zscore_cells(Yb, bounds_b)[None])
+        total_s = self._run_perm(eng_c, k, 1, cols=A0)[0].sum()
+        org_s = np.sqrt(s ** 2 / np.sum(s ** 2) * total_s)
+
+        draws = self._draw_on_rank0(lambda: self._draw_behaviour_perms(Yb, niter, True))
+        task_perm, beh_perm = draws[:, :n], draws[:, n:]
+        # task rows of resample r: W P_r  (column i collects W's columns r with perm[r] == i)
+        task_rows = np.zeros((niter, ng * nc, n))
+        ridx = np.arange(niter)[:, None]
+        task_rows[ridx, :, task_perm] = self._W.T[None]      # [r, :, perm[r, q]] = W[:, q]
+        A = raw_rows(task_rows, cf.zscore_cells(Yb[beh_perm], bounds_b))
+        rownorm2 = self._run_perm(eng_c, k, niter, cols=A)                       # R x k row norms^2
+        total_hat = rownorm2.sum(axis=1)                                         # :419
+        with np.errstate(divide="ignore", invalid="ignore"):
+            scaledU = U[None] / np.sqrt(rownorm2)[:, :, None]                    # D^-1 U per resample
+        cols = np.einsum("rki,rkj->rji", A, scaledU)
+        s_hat = np.sqrt(self._run_perm(eng_c, k, niter, cols=cols))              # :404-405
+        per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)          # quirk Q3 (:421-423)
+        s_hat = np.sqrt(per_hat * total_hat[:, None])                             # :424
+        ratio, step = self._ratios(s_hat, org_s, org_s, niter)
+        debug = {"s_list": s_hat, "indices": draws, "org_s": org_s}
+        return ratio, step, debug
+
+    # ------------------------------------------------------------------
+    # bootstrap test (mct)
     # ------------------------------------------------------------------
     def _bootstrap_test(self, U, s, V, niter, Tvsc_orig, CI, keep_right_sv):
         """bootstrap_permutation.py:467-766 for mct, streaming form."""
@@ -145,8 +293,7 @@ class _ResampleTestPLS(ResampleTest):
         U = np.asarray(U, dtype=float)
         V = np.asarray(V, dtype=float)
         rank, nranks = dist.world()
-        inds = resample.bootstraps(co, niter) if rank == 0 else None
-        inds = dist.broadcast_indices(inds, eng.device)
+        inds = self._draw_on_rank0(lambda: resample.bootstraps(co, niter))
         lo, hi = dist.shard_bounds(niter, rank, nranks)
         M = self._W.T @ U
         Wm = operators.cell_mean_operator(co)

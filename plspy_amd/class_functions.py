@@ -1,0 +1,134 @@
+"""Host-side helpers on SMALL matrices (n x k latents, n x b behaviour data,
+k x k singular vectors).  Everything that touches the n x p data goes through
+the GPU engine; these NumPy functions only serve the observed-decomposition
+bookkeeping and the tiny per-resample tables, with the reference's conventions
+(plspy/core/class_functions.py)."""
+import warnings
+
+import numpy as np
+
+
+def cell_bounds(cond_order):
+    """Row ranges of the group x condition cells, in row order."""
+    lo = [0]
+    for sizes in np.asarray(cond_order):
+        for sz in sizes:
+            lo.append(lo[-1] + int(sz))
+    return np.array(lo, dtype=np.int64)
+
+
+def group_stds(M, cond_order):
+    """np.std (ddof 0) of every column within each group's rows
+    (class_functions.py:314-368 with return_std=True; also used by the
+    degenerate-behaviour guard, which slices with the FULL cond_order even on
+    the bscan subset -- quirk Q8 -- hence the tolerant slicing)."""
+    cond_order = np.asarray(cond_order)
+    out = np.empty((len(cond_order), M.shape[-1]))
+    start = 0
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        for g, tot in enumerate(cond_order.sum(axis=1)):
+            out[g] = np.std(M[start:start + tot], axis=0)
+            start += int(tot)
+    return out
+
+
+def zscore_cells(M, bounds):
+    """Per-cell z-score (ddof 0) divided by sqrt(n_cell), constant columns -> 0:
+    what class_functions.py:221-238 does to X and to Y (scipy.stats.zscore's
+    constant-slice rule + nan_to_num).  M: (..., n, b); cells along axis -2."""
+    out = np.zeros_like(M, dtype=float)
+    eps = np.finfo(float).eps
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        blk = M[..., lo:hi, :]
+        mu = blk.mean(axis=-2, keepdims=True)
+        sd = np.sqrt(np.mean((blk - mu) ** 2, axis=-2, keepdims=True))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            z = (blk - mu) / sd / np.sqrt(hi - lo)
+        dead = np.broadcast_to(~(sd > eps * np.abs(mu)), z.shape)
+        out[..., lo:hi, :] = np.where(dead, 0.0, z)
+    return out
+
+
+def compute_corr_small(L, Y, cond_order):
+    """_compute_corr (class_functions.py:185-247) for a small left matrix
+    (latent scores n x k): stacked per-cell Yz.T @ Lz, (cells*b) x k."""
+    bounds = cell_bounds(cond_order)
+    Lz = zscore_cells(np.asarray(L, dtype=float), bounds)
+    Yz = zscore_cells(np.asarray(Y, dtype=float), bounds)
+    return np.vstack([Yz[lo:hi].T @ Lz[lo:hi] for lo, hi in zip(bounds[:-1], bounds[1:])])
+
+
+def corr_operator(Yz, bounds):
+    """(cells*b) x n operator A with  A @ Xz == stacked per-cell Yz.T @ Xz,
+    Xz being the per-cell z-scored data (the behaviour half of _compute_corr,
+    class_functions.py:240-242, as a block-diagonal matrix)."""
+    n, b = Yz.shape
+    ncell = len(bounds) - 1
+    A = np.zeros((ncell * b, n))
+    for c, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        A[c * b:(c + 1) * b, lo:hi] = Yz[lo:hi].T
+    return A
+
+
+def normalize(M):
+    """Column L2 normalisation, zero columns stay zero (class_functions.py:693-708)."""
+    base = np.linalg.norm(M, axis=0)
+    if np.any(base == 0):
+        warnings.warn("_normalize: encountered column(s) with zero norm; "
+                      "these will be returned as zero vectors.", RuntimeWarning)
+    out = np.zeros_like(M, dtype=float)
+    np.divide(M, base, out=out, where=base != 0)
+    return out
+
+
+def compute_Y_latents(Y, U, cond_order):
+    """class_functions.py:250-276: per cell, Y_cell @ U_cell."""
+    bounds = cell_bounds(cond_order)
+    b = Y.shape[1]
+    out = np.empty((Y.shape[0], U.shape[1]))
+    for c, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        out[lo:hi] = Y[lo:hi] @ U[c * b:(c + 1) * b]
+    return out
+
+
+def bscan_mask(cond_order, bscan):
+    """Rows of X / Y that belong to the conditions in bscan (pls_classes.py:1430-1441)."""
+    mask = []
+    for sizes in np.asarray(cond_order):
+        for ci, sz in enumerate(sizes):
+            mask.extend([ci in bscan] * int(sz))
+    return np.array(mask, dtype=bool)
+
+
+def split_Tu_Bu(U, n_cond, n_behav, n_groups, n_bscan):
+    """class_functions.py:518-578: task / behaviour rows of the multiblock U."""
+    per = n_cond + n_bscan * n_behav
+    Tu = np.vstack([U[g * per:g * per + n_cond] for g in range(n_groups)])
+    Bu = np.vstack([U[g * per + n_cond:(g + 1) * per] for g in range(n_groups)])
+    return Tu, Bu
+
+
+def get_Tusc(Tu, n_cond, cond_order):
+    """class_functions.py:580-625: each condition's row of Tu repeated per subject."""
+    rows = []
+    for g, sizes in enumerate(np.asarray(cond_order)):
+        for c in range(n_cond):
+            rows.append(np.tile(Tu[g * n_cond + c:g * n_cond + c + 1], (int(sizes[c]), 1)))
+    return np.vstack(rows)
+
+
+def get_Busc(Bu, Ybscan, cond_order, bscan):
+    """class_functions.py:628-690: behaviour scores Ybscan_cell @ Bu_cell (uses the
+    first condition's subject count for every condition of a group, like the
+    reference)."""
+    cond_order = np.asarray(cond_order)
+    nb = len(bscan)
+    b = Ybscan.shape[1]
+    out = []
+    for g, sizes in enumerate(cond_order):
+        ns = int(sizes[0])
+        span = int(sum(cond_order[:g, 0])) * nb
+        for c in range(nb):
+            out.append(Ybscan[span + ns * c:span + ns * (c + 1)] @ Bu[b * (c + nb * g):b * (c + 1 + nb * g)])
+    return np.vstack(out)

@@ -345,7 +345,7 @@ struct GramPlan {
   size_t lds, part_elems, bytes;
 };
 
-bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, GramPlan &g) {
+bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, bool per_item_x, GramPlan &g) {
   if (n <= 0 || m <= 0 || items <= 0 || p <= 0) return false;
   const int nk = (n + 3) / 4;
   g.MC = (m + 15) / 16;
@@ -356,7 +356,7 @@ bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, GramPlan &g) {
   const int ncand = g.MC == 1 ? 4 : (g.MC == 2 ? 2 : 1);
   g.B = 0;
   for (int i = 0; i < ncand; ++i) {
-    if (cand[i] > 1 && cand[i] > items) continue;
+    if (cand[i] > 1 && (cand[i] > items || per_item_x)) continue;   // items with their own X do not share a tile
     // operator fragments may take at most 96 KiB; the rest stages rows of X
     if ((size_t)cand[i] * g.MC * nk * 512 <= 96 * 1024) {
       g.B = cand[i];
@@ -413,20 +413,22 @@ extern "C" int plsr_ops_pack_rows(const double *d_rows, int32_t items, int32_t m
   return check_launch();
 }
 
-extern "C" size_t plsr_gram_workspace_bytes(int32_t n, int32_t m, int32_t items, int64_t p) {
+extern "C" size_t plsr_gram_workspace_bytes(int32_t n, int32_t m, int32_t items, int64_t p,
+                                            int64_t x_item_stride) {
   GramPlan g;
-  return gram_plan(n, m, items, p, g) ? g.bytes : 0;
+  return gram_plan(n, m, items, p, x_item_stride != 0, g) ? g.bytes : 0;
 }
 
-extern "C" int plsr_gram_batch(const double *d_X, int64_t ldx, int64_t p, int32_t n,
-                               const double *d_frag, int32_t items, int32_t m, double *d_G,
-                               void *d_work, size_t work_bytes, void *stream) {
-  if (!d_X || !d_frag || !d_G || !d_work || ldx < p) return PLSR_EINVAL;
+extern "C" int plsr_gram_batch(const double *d_X, int64_t x_item_stride, int64_t ldx, int64_t p,
+                               int32_t n, const double *d_frag, int32_t items, int32_t m,
+                               double *d_G, void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_frag || !d_G || !d_work || ldx < p || x_item_stride < 0) return PLSR_EINVAL;
   GramPlan g;
-  if (!gram_plan(n, m, items, p, g)) return PLSR_EUNSUPPORTED;
+  if (!gram_plan(n, m, items, p, x_item_stride != 0, g)) return PLSR_EUNSUPPORTED;
   if (g.bytes > work_bytes) return PLSR_EWORKSPACE;
   GramArgs a;
   a.X = d_X;
+  a.x_item_stride = x_item_stride;
   a.ldx = ldx;
   a.p = p;
   a.n = n;
@@ -458,5 +460,33 @@ extern "C" int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t l
   if (k > EIG_MAX) return PLSR_EUNSUPPORTED;
   hipLaunchKernelGGL(eigh_kernel, dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream, d_G,
                      item_stride, ld, off, k, count, d_evals, d_evecs, 30);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// K3: gather + per-cell z-score
+// ---------------------------------------------------------------------------
+#include "plsr_corr.hip.h"
+
+extern "C" int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, const int32_t *d_src,
+                                  int32_t items, int32_t nout, const int32_t *d_cell_lo,
+                                  const int32_t *d_cell_z, int32_t ncell, double *d_out,
+                                  int64_t ldo, void *stream) {
+  if (!d_X || !d_src || !d_cell_lo || !d_cell_z || !d_out || items <= 0 || nout <= 0 ||
+      ncell <= 0 || p <= 0 || ldx < p || ldo < p)
+    return PLSR_EINVAL;
+  GatherArgs a;
+  a.X = d_X;
+  a.ldx = ldx;
+  a.p = p;
+  a.src = d_src;
+  a.cell_lo = d_cell_lo;
+  a.cell_z = d_cell_z;
+  a.nout = nout;
+  a.ncell = ncell;
+  a.out = d_out;
+  a.ldo = ldo;
+  hipLaunchKernelGGL(gather_zscore_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)items),
+                     dim3(256), 0, (hipStream_t)stream, a);
   return check_launch();
 }

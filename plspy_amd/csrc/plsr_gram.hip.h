@@ -28,6 +28,7 @@ namespace plsr {
 
 struct GramArgs {
   const double *X;
+  int64_t x_item_stride;     // 0: every item uses the same X; else doubles between items' matrices
   int64_t ldx, p;
   int32_t n, nk;
   const double *frag;    // [items*MC][nk][64], rows layout
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
   const int g = lane >> 4;
   const int nrows = A.nk * 4;
   const int item0 = blockIdx.x * B;
+  const double *Xi = A.X + (int64_t)item0 * A.x_item_stride;   // B == 1 whenever the stride is non-zero
   const int chunk = blockIdx.y;
 
   double *ops = smem;                                   // [B][MC][nk][64]
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
         for (int u = 0; u < 4; ++u) {
           const int row = r0 + u * 4 + (tid >> 6);
           const int64_t v = v0 + lane;
-          tmp[u] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+          tmp[u] = (row < A.n && v < A.p) ? Xi[(int64_t)row * A.ldx + v] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -159,15 +159,21 @@ class ProjectionEngine:
         return torch.cat(out, dim=0)
 
     # -- K2: Gram / thin SVD -------------------------------------------------
-    def gram_phase(self, rows):
-        """rows: (S, m, n) operator rows (NumPy).  Returns the (S, mm, mm) Grams
-        (A_s X)(A_s X)^T on the device, mm = 16*ceil(m/16)."""
+    def gram_phase(self, rows, gather=None):
+        """rows: (S, m, n') operator rows (NumPy).  Returns the (S, mm, mm) Grams
+        (A_s Z_s)(A_s Z_s)^T on the device, mm = 16*ceil(m/16).
+
+        gather=None: Z_s = X for every item (n' = n).  Otherwise gather is a
+        dict(src=(S, n') int32, cell_lo, cell_z) and Z_s is the item's own
+        gathered / per-cell z-scored copy of X (gather_zscore), made in chunks."""
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         S, m, n = rows.shape
-        assert n == self.n
+        assert n == (self.n if gather is None else gather["src"].shape[1])
         mm = (m + 15) // 16 * 16
         G = torch.empty((S, mm, mm), dtype=torch.float64, device=self.device)
         per_item = self.lib.plsr_rows_frag_elems(n, m, 1) * 8 + m * n * 8
+        if gather is not None:
+            per_item += n * self.p * 8
         step = max(1, min(S, self.work_limit // max(per_item, 1)))
         for lo in range(0, S, step):
             hi = min(S, lo + step)
@@ -177,14 +183,40 @@ class ProjectionEngine:
                                device=self.device)
             _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_rows), cnt, m, n, _ptr(frag), _stream()),
                        "plsr_ops_pack_rows")
-            need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p)
+            if gather is None:
+                Z, zstride = self.X, 0
+            else:
+                Z = self.gather_zscore(gather["src"][lo:hi], gather["cell_lo"], gather["cell_z"])
+                zstride = Z.stride(0)
+            need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p, zstride)
             if need == 0:
                 raise _lib.PlsrError(f"plsr_gram: unsupported shape n={n} m={m}")
             work = torch.empty(need, dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.plsr_gram_batch(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(frag),
+            ldz = self.X.stride(0) if gather is None else Z.stride(1)
+            _lib.check(self.lib.plsr_gram_batch(_ptr(Z), zstride, ldz, self.p, n, _ptr(frag),
                                                 cnt, m, _ptr(G[lo:hi]), _ptr(work), need, _stream()),
                        "plsr_gram_batch")
         return G
+
+    def gather_zscore(self, src, cell_lo, cell_z):
+        """(items, nout, p) tensor: rows of X gathered by src (items x nout) and
+        z-scored (ddof 0, / sqrt(n_cell)) within the output-row cells flagged in
+        cell_z; other cells are plain copies.  The data side of _compute_corr."""
+        src = np.ascontiguousarray(np.atleast_2d(src), dtype=np.int32)
+        items, nout = src.shape
+        cell_lo = np.ascontiguousarray(cell_lo, dtype=np.int32)
+        cell_z = np.ascontiguousarray(cell_z, dtype=np.int32)
+        assert cell_lo[0] == 0 and cell_lo[-1] == nout and len(cell_z) == len(cell_lo) - 1
+        out = torch.empty((items, nout, self.p), dtype=torch.float64, device=self.device)
+        # keep the small device arrays referenced until the launch is enqueued:
+        # a temporary freed between two allocations would be reused by the next
+        d_src = self.dev(src, torch.int32)
+        d_lo = self.dev(cell_lo, torch.int32)
+        d_z = self.dev(cell_z, torch.int32)
+        _lib.check(self.lib.plsr_gather_zscore(
+            _ptr(self.X), self.X.stride(0), self.p, _ptr(d_src), items, nout, _ptr(d_lo), _ptr(d_z),
+            len(cell_z), _ptr(out), self.p, _stream()), "plsr_gather_zscore")
+        return out
 
     def eigh(self, G, off, k):
         """Eigen-decomposition of the k x k diagonal block at `off` of every

@@ -6,6 +6,8 @@ from . import pls_classes
 
 methods = {
     "mct": pls_classes._MeanCentreTaskPLS,
+    "rb": pls_classes._RegularBehaviourPLS,
+    "mb": pls_classes._MultiblockPLS,
 }
 
 

@@ -11,6 +11,7 @@ import abc
 import numpy as np
 
 from . import bootstrap_permutation, exceptions, operators
+from . import class_functions as cf
 from .engine import ProjectionEngine
 
 
@@ -160,3 +161,164 @@ class _MeanCentreTaskPLS(PLSBase):
 
         # swap U and V to be consistent with MATLAB PLS (pls_classes.py:323)
         self.U, self.V = self.V, self.U
+
+
+def _check_behaviour(Y, cond_order):
+    """pls_classes.py:561-564 / :1446-1449."""
+    if (cf.group_stds(Y, cond_order) == 0).any():
+        raise Exception("Please check your behaviour data, and make sure that none of the "
+                        "columns are all the same for each group.")
+
+
+@PLSBase._register_subclass("rb")
+class _RegularBehaviourPLS(PLSBase):
+    """Regular behaviour PLS (pls_classes.py:386-647).  Defaults num_perm = 0,
+    num_boot = 0 like the reference (:503-504)."""
+
+    def __init__(self, X, groups_sizes, num_conditions, Y=None, cond_order=None,
+                 num_perm=0, num_boot=0, CI=0.95, **kwargs):
+        self._take_kwargs(kwargs)
+        if Y is None:
+            raise exceptions.MissingParameterError("Please provide a Y/behavioural matrix.")
+        if "contrasts" in kwargs:
+            raise ValueError(f"Do not provide a contrast matrix for {self._pls_types[self.pls_alg]}.")
+        if len(X.shape) != 2 or len(Y.shape) != 2:
+            raise exceptions.ImproperShapeError("Input matrices must be 2-dimensional.")
+        self.X, self.Y = X, Y
+        self.groups_sizes, self.num_groups = self._get_groups_info(groups_sizes)
+        self.num_conditions = num_conditions
+        self.cond_order = self._resolve_cond_order(cond_order, groups_sizes, num_conditions, X, Y)
+        _check_behaviour(self.Y, self.cond_order)
+        self.num_perm, self.num_boot, self.CI = num_perm, num_boot, CI
+
+        engine = ProjectionEngine(X)
+        co = np.asarray(self.cond_order)
+        bounds = cf.cell_bounds(co)
+        n = X.shape[0]
+        # R = per-cell Yz.T @ Xz (class_functions.py:185-247): Xz on the device
+        # (gather_zscore), the k x n behaviour operator from the tiny Y
+        Xz = engine.gather_zscore(np.arange(n), bounds, np.ones(len(bounds) - 1))[0]
+        eng_z = ProjectionEngine(Xz, device=engine.device, work_limit=engine.work_limit)
+        A = cf.corr_operator(cf.zscore_cells(np.asarray(Y, dtype=float), bounds), bounds)
+        self.R = eng_z.apply_operator(A).cpu().numpy()
+        self.U, self.s, self.V = eng_z.thin_svd(A)                     # :574
+        self.X_latent = np.dot(self.X, self.V)
+        self.Y_latent = cf.compute_Y_latents(self.Y, self.U, co)
+        self.lvcorrs = cf.compute_corr_small(self.X_latent, self.Y, co)   # :581-583
+
+        self.resample_tests = bootstrap_permutation.ResampleTest._create(
+            self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, None,
+            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, lvcorrs_orig=self.lvcorrs,
+            CI=self.CI, engine=engine)
+
+        if "num_split" in self._user_defined_attrs:
+            self.num_split = int(self.num_split)
+            if self.num_split > 0:
+                from . import split_half_resampling
+                self._clip_lv()
+                self.pls_repro_tt = split_half_resampling.split_half_test_train(
+                    self.pls_alg, self.X, self.Y, self.cond_order, num_split=self.num_split,
+                    mctype=None, contrasts=None, engine=engine)
+                self.pls_repro_sh = split_half_resampling.split_half(
+                    self.pls_alg, self.X, self.Y, self.cond_order, num_split=self.num_split,
+                    mctype=None, contrasts=None, lv=self.lv, CI=self.CI, engine=engine)
+        self.U, self.V = self.V, self.U                                 # :646
+
+
+@PLSBase._register_subclass("mb")
+class _MultiblockPLS(PLSBase):
+    """Multiblock PLS (pls_classes.py:1206-1558)."""
+
+    def __init__(self, X, groups_sizes, num_conditions, mctype=0, Y=None, cond_order=None,
+                 num_perm=1000, num_boot=1000, CI=0.95, **kwargs):
+        self._take_kwargs(kwargs)
+        if Y is None:
+            raise exceptions.MissingParameterError("Please provide a Y/behavioural matrix.")
+        if "contrasts" in kwargs:
+            raise ValueError(f"Do not provide a contrast matrix for {self._pls_types[self.pls_alg]}.")
+        if len(X.shape) != 2 or len(Y.shape) != 2:
+            raise exceptions.ImproperShapeError("Input matrices must be 2-dimensional.")
+        self.X, self.Y = X, Y
+        self.groups_sizes, self.num_groups = self._get_groups_info(groups_sizes)
+        self.num_conditions = num_conditions
+        if num_conditions == 1 and mctype != 1:
+            print("Because you are running single condition Task PLS, "
+                  "input Mean-Centering Type has to set to 1")
+            self.mctype = 1
+        else:
+            self.mctype = mctype
+        self.cond_order = self._resolve_cond_order(cond_order, groups_sizes, num_conditions, X, Y)
+        if "bscan" not in self._user_defined_attrs:               # :1400-1409 (0-based, quirk Q19)
+            self.bscan = [i for i in range(self.num_conditions)]
+        else:
+            if self.bscan != sorted(self.bscan):
+                print("provided bscan not in ascending order - conditions in bscan will be correctly reordered")
+            if any(item < 0 or item > self.num_conditions - 1 for item in self.bscan):
+                print(f"bscan should be a subset of: 1 to {self.num_conditions}")
+        self.num_perm, self.num_boot, self.CI = num_perm, num_boot, CI
+
+        co = np.asarray(self.cond_order)
+        bscan = list(self.bscan)
+        mask = cf.bscan_mask(co, bscan)
+        self.Xbscan, self.Ybscan = self.X[mask], self.Y[mask]
+        _check_behaviour(self.Ybscan, co[:, bscan])
+
+        engine = ProjectionEngine(X)
+        ng, nc = co.shape
+        n = X.shape[0]
+        nb, b = self.Ybscan.shape
+        nbs = len(bscan)
+        per = nc + nbs * b
+        k = ng * per
+        bounds_b = cf.cell_bounds(co[:, bscan])
+        # stacked device matrix [X; bscan rows of X z-scored within cells]
+        Xzb = engine.gather_zscore(np.flatnonzero(mask), bounds_b, np.ones(len(bounds_b) - 1))[0]
+        import torch
+        eng_c = ProjectionEngine(torch.cat((engine.X, Xzb), dim=0), device=engine.device,
+                                 work_limit=engine.work_limit)
+        W = operators.mean_centre_operator(co, self.mctype)
+        Ab = cf.corr_operator(cf.zscore_cells(np.asarray(self.Ybscan, dtype=float), bounds_b), bounds_b)
+        raw = np.zeros((k, n + nb))                                 # class_functions.py:479-511, rows per group
+        for g in range(ng):
+            raw[g * per:g * per + nc, :n] = W[g * nc:(g + 1) * nc]
+            raw[g * per + nc:(g + 1) * per, n:] = Ab[g * nbs * b:(g + 1) * nbs * b]
+        G = eng_c.gram_phase(raw[None])[0].cpu().numpy()
+        rownorm = np.sqrt(np.diag(G)[:k])
+        normed = raw / rownorm[:, None]                              # :503-505 folded into the operator
+        self.multiblock = eng_c.apply_operator(normed).cpu().numpy()
+        self.U, self.s, self.V = eng_c.thin_svd(normed)              # :1456
+
+        V_normed = cf.normalize(self.V)
+        T_X_latent = np.dot(self.X, V_normed)                        # :1460-1461
+        B_X_latent = np.dot(self.Xbscan, self.V)                     # :1464
+        self.X_latent = np.vstack((T_X_latent, B_X_latent))
+        self.usc, self.Tusc, self.Busc = self.X_latent, T_X_latent, B_X_latent
+        Tu, Bu = cf.split_Tu_Bu(self.U, num_conditions, self.Y.shape[1], ng, nbs)
+        Tusc = cf.get_Tusc(Tu, num_conditions, co)
+        Busc = cf.get_Busc(Bu, self.Ybscan, co, bscan)
+        Tvsc_orig = operators.cell_mean_operator(co) @ T_X_latent    # :1485
+        self.Bvsc, self.Tvsc, self.Tv, self.Bv = Busc, Tusc, Tu, Bu
+        self.Y_latent = np.vstack([Tusc, Busc])
+        self.vsc = self.Y_latent
+        self.lvcorrs = cf.compute_corr_small(B_X_latent, self.Ybscan, co[:, bscan])   # :1499-1501
+
+        self.resample_tests = bootstrap_permutation.ResampleTest._create(
+            self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, self.mctype,
+            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, bscan=self.bscan,
+            Xbscan=self.Xbscan, Ybscan=self.Ybscan, lvcorrs_orig=self.lvcorrs,
+            Tvsc_orig=Tvsc_orig, CI=self.CI, engine=engine)
+
+        if "num_split" in self._user_defined_attrs:
+            self.num_split = int(self.num_split)
+            if self.num_split > 0:
+                from . import split_half_resampling
+                self._clip_lv()
+                self.pls_repro_tt = split_half_resampling.split_half_test_train(
+                    self.pls_alg, self.X, self.Y, self.cond_order, num_split=self.num_split,
+                    mctype=self.mctype, contrasts=None, bscan=self.bscan, Xbscan=self.Xbscan,
+                    Ybscan=self.Ybscan, engine=engine)
+                self.pls_repro_sh = split_half_resampling.split_half(
+                    self.pls_alg, self.X, self.Y, self.cond_order, num_split=self.num_split,
+                    mctype=self.mctype, contrasts=None, bscan=self.bscan, Xbscan=self.Xbscan,
+                    Ybscan=self.Ybscan, lv=self.lv, CI=self.CI, engine=engine)
+        self.U, self.V = self.V, self.U                              # :1557

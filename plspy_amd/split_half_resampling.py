@@ -4,10 +4,10 @@ split_half :404-861).
 
 Per split the reference gathers both halves of X, preprocesses them, runs a
 LAPACK SVD on each (k x p) block and multiplies the singular vectors.  Here a
-split is one *item* of the Gram kernel: the two halves' operators (rows of
-``W_half @ P_half``) are stacked, the kernel returns
+split is one *item* of the Gram kernel: the two halves' operators are stacked,
+the kernel returns
 
-    G = [M1; M2] [M1; M2]^T      M_h = A_h X  (never stored)
+    G = [M1; M2] [M1; M2]^T      M_h = A_h Z   (never stored)
 
 and everything the reference derives from the SVDs follows from the k x k
 blocks G11, G12, G22 and the Jacobi eigen-decompositions of G11 / G22:
@@ -17,6 +17,14 @@ blocks G11, G12, G22 and the Jacobi eigen-decompositions of G11 / G22:
     V1^T V2               = S1^-1 U1^T G12 U2 S2^-1           (:682)
     U1^T U2                                                    (:683)
 
+Z is X itself for task PLS (the half's mean-centring and row selection are a
+linear operator).  For behaviour / multiblock PLS each half's correlation block
+z-scores X within the half's cells, which depends on the split, so every item
+gets its own gathered + z-scored copy of the rows it needs (gather_zscore, K3)
+and A_h holds the z-scored behaviour columns.  The multiblock row normalisation
+over all voxels (class_functions.py:503-505) is applied to G afterwards
+(G_ij / (|row_i| |row_j|), |row_i|^2 = G_ii).
+
 Random draws follow the reference's np.random call order.  Signs of singular
 vectors are arbitrary in the reference (LAPACK) and here (Jacobi); the summary
 statistics use absolute values of the diagonal and are sign-free.  Latent
@@ -24,7 +32,9 @@ variables that are null by construction (rank-deficient mean-centring) have
 arbitrary vectors in the reference; here their singular value is deflated to 0
 and their entries are 0."""
 import numpy as np
+import torch
 
+from . import class_functions as cf
 from . import dist, exceptions, operators, resample
 from .engine import ProjectionEngine
 
@@ -38,67 +48,152 @@ def _get_cond_order(X_shape, groups_tuple, num_conditions):
     return np.array([np.array([i] * num_conditions) for i in groups_tuple])
 
 
-def _draw_splits(cond_order, num_split, n, task):
-    """Index vectors of every real and null split, in the reference's RNG order
-    (:119-153, :266-283).  Returns (real [(idx1, idx2)], null [(idx1, idx2)],
-    group sizes of half 1 / half 2).  For task variants the null split is
-    composed with the full row permutation of X (:282-283)."""
+def _draw_splits(pls_alg, cond_order, num_split, n, bscan):
+    """Every real and null split, in the reference's RNG order (:119-169,
+    :266-283, :316).  Each entry: dict(x1, x2 = rows of X per half; y1, y2 =
+    rows of Y per half (rb: permuted in the null, :316-318); b1, b2 = bscan rows
+    per half (mb); xb1, xb2 = rows of X for the bscan part (mb: through the
+    null's row permutation of X, :282-283, :358)).  Returns (splits, g1, g2)."""
     tables = resample.subject_tables(cond_order)
     alltab = np.concatenate(tables)
     nc = alltab.shape[1]
-    real = []
+    mb = pls_alg == "mb"
+    out = []
     g1 = g2 = None
     for _ in range(num_split):
-        p1, p2, g1, g2 = [], [], [], []
+        p1, p2, q1, q2, g1, g2 = [], [], [], [], [], []
         for tbl in tables:
             ns = tbl.shape[0]
             half = int(np.floor(ns / 2))
-            t = tbl[np.random.permutation(ns), :]
+            t = tbl[np.random.permutation(ns), :]                    # :136
             p1.append(t[:half, :].flatten())
             p2.append(t[half:, :].flatten())
             g1.append(len(p1[-1]) // nc)
             g2.append(len(p2[-1]) // nc)
-        real.append((np.concatenate(p1), np.concatenate(p2)))
-    null = []
-    half = sum(g1)
+            if mb:
+                q1.append(t[:half][:, bscan].flatten())              # :160-161
+                q2.append(t[half:][:, bscan].flatten())
+        x1, x2 = np.concatenate(p1), np.concatenate(p2)
+        d = dict(x1=x1, x2=x2, y1=x1, y2=x2)
+        if mb:
+            d.update(b1=np.concatenate(q1), b2=np.concatenate(q2))
+            d.update(xb1=d["b1"], xb2=d["b2"])
+        out.append(d)
+    half = sum(g1)                                                   # :270 (last split's sizes, quirk Q12)
     for _ in range(num_split):
-        t = alltab[np.random.permutation(n // nc), :]
+        t = alltab[np.random.permutation(n // nc), :]                # :271
         i1, i2 = t[:half, :].flatten(), t[half:, :].flatten()
-        if task:
-            perm = np.random.permutation(n)
-            i1, i2 = perm[i1], perm[i2]
-        null.append((i1, i2))
-    return real, null, g1, g2
+        d = dict(x1=i1, x2=i2, y1=i1, y2=i2)
+        if mb:
+            d.update(b1=t[:half][:, bscan].flatten(), b2=t[half:][:, bscan].flatten())
+        if pls_alg in ("mct", "mb"):
+            perm = np.random.permutation(n)                          # :282
+            d.update(x1=perm[i1], x2=perm[i2])
+            if mb:
+                d.update(xb1=perm[d["b1"]], xb2=perm[d["b2"]])       # :358: permx rows, unpermuted Y rows
+        else:
+            permy = np.random.permutation(n)                         # :316
+            d.update(y1=permy[i1], y2=permy[i2])
+        out.append(d)
+    return out, g1, g2
 
 
-def _mct_items(cond_order, mctype, n, pairs, g1, g2):
-    """Stacked operator rows [W1 P1; W2 P2] (2k x n) for every split."""
+def _items_mct(cond_order, mctype, n, splits, g1, g2):
+    """Stacked operator rows [W1 P1; W2 P2] (2k x n) for every split; Z = X."""
     nc = np.asarray(cond_order).shape[1]
     W1 = operators.mean_centre_operator(_get_cond_order((sum(g1) * nc,), tuple(g1), nc), mctype)
     W2 = operators.mean_centre_operator(_get_cond_order((sum(g2) * nc,), tuple(g2), nc), mctype)
     k = W1.shape[0]
-    rows = np.zeros((len(pairs), 2 * k, n))
-    for i, (i1, i2) in enumerate(pairs):
-        rows[i, :k, i1] = W1.T          # half-1 row r of the gathered block is X[i1[r]]
-        rows[i, k:, i2] = W2.T
-    return rows, k
+    rows = np.zeros((len(splits), 2 * k, n))
+    for i, d in enumerate(splits):
+        rows[i, :k, d["x1"]] = W1.T          # half-1 row r of the gathered block is X[x1[r]]
+        rows[i, k:, d["x2"]] = W2.T
+    return rows, None, k
 
 
-def _decompose(engine, rows, k):
+def _items_rb(cond_order, Y, splits, g1, g2):
+    """Behaviour PLS: item matrix = [half 1 rows; half 2 rows] z-scored within
+    each half's cells; operator rows = the halves' z-scored behaviour columns
+    (R_h = Yz_h.T @ Xz_h, class_functions.py:185-247 via :203-204)."""
+    nc = np.asarray(cond_order).shape[1]
+    co1 = _get_cond_order((sum(g1) * nc,), tuple(g1), nc)
+    co2 = _get_cond_order((sum(g2) * nc,), tuple(g2), nc)
+    b1, b2 = cf.cell_bounds(co1), cf.cell_bounds(co2)
+    n1 = int(b1[-1])
+    n = n1 + int(b2[-1])
+    Y = np.asarray(Y, dtype=float)
+    k = (len(b1) - 1) * Y.shape[1]
+    rows = np.zeros((len(splits), 2 * k, n))
+    src = np.empty((len(splits), n), dtype=np.int32)
+    for i, d in enumerate(splits):
+        src[i, :n1], src[i, n1:] = d["x1"], d["x2"]
+        rows[i, :k, :n1] = cf.corr_operator(cf.zscore_cells(Y[d["y1"]], b1), b1)
+        rows[i, k:, n1:] = cf.corr_operator(cf.zscore_cells(Y[d["y2"]], b2), b2)
+    cell_lo = np.concatenate((b1, n1 + b2[1:]))
+    gather = dict(src=src, cell_lo=cell_lo, cell_z=np.ones(len(cell_lo) - 1, dtype=np.int32))
+    return rows, gather, k
+
+
+def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2):
+    """Multiblock PLS: item matrix = [half-1 rows, half-2 rows (raw) ; half-1
+    bscan rows, half-2 bscan rows (z-scored within the half's bscan cells)];
+    operator rows per half and group = [mean-centring rows ; z-scored behaviour
+    columns] (class_functions.py:454-516 without the row normalisation, which is
+    applied to the Gram)."""
+    cond_order = np.asarray(cond_order)
+    ng, nc = cond_order.shape
+    nbs = len(bscan)
+    Y = np.asarray(Y, dtype=float)
+    b = Y.shape[1]
+    per = nc + nbs * b
+    k = ng * per
+    halves = []
+    for gs in (g1, g2):
+        co = _get_cond_order((sum(gs) * nc,), tuple(gs), nc)
+        halves.append(dict(W=operators.mean_centre_operator(co, mctype), n=int(co.sum()),
+                           bb=cf.cell_bounds(co[:, bscan])))
+    n1, n2 = halves[0]["n"], halves[1]["n"]
+    nb1, nb2 = int(halves[0]["bb"][-1]), int(halves[1]["bb"][-1])
+    n = n1 + n2
+    width = n + nb1 + nb2
+    rows = np.zeros((len(splits), 2 * k, width))
+    src = np.empty((len(splits), width), dtype=np.int32)
+    for i, d in enumerate(splits):
+        src[i] = np.concatenate((d["x1"], d["x2"], d["xb1"], d["xb2"]))
+        for h, (xoff, boff, key) in enumerate(((0, n, "b1"), (n1, n + nb1, "b2"))):
+            hv = halves[h]
+            Ab = cf.corr_operator(cf.zscore_cells(Y[d[key]], hv["bb"]), hv["bb"])
+            for g in range(ng):
+                r0 = h * k + g * per
+                rows[i, r0:r0 + nc, xoff:xoff + hv["n"]] = hv["W"][g * nc:(g + 1) * nc]
+                rows[i, r0 + nc:r0 + per, boff:boff + Ab.shape[1]] = Ab[g * nbs * b:(g + 1) * nbs * b]
+    cell_lo = np.concatenate(([0, n], n + halves[0]["bb"][1:], n + nb1 + halves[1]["bb"][1:]))
+    cell_z = np.ones(len(cell_lo) - 1, dtype=np.int32)
+    cell_z[0] = 0                                    # the task rows are used raw
+    return rows, dict(src=src, cell_lo=cell_lo, cell_z=cell_z), k
+
+
+def _decompose(engine, rows, gather, k, row_normalise):
     """Per item: U1, s1, U2, s2 (NumPy) and G12."""
     rank, nranks = dist.world()
     S = rows.shape[0]
     lo, hi = dist.shard_bounds(S, rank, nranks)
-    G = engine.gram_phase(rows[lo:hi]) if hi > lo else None
-    if G is None:
-        import torch
-        mm = (2 * k + 15) // 16 * 16
+    mm = (2 * k + 15) // 16 * 16
+    if hi > lo:
+        sub = None if gather is None else dict(gather, src=gather["src"][lo:hi])
+        G = engine.gram_phase(rows[lo:hi], gather=sub)
+        if row_normalise:
+            Gh = G.cpu().numpy()
+            d = np.sqrt(np.einsum("sii->si", Gh))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                Gh = np.where((d[:, :, None] * d[:, None, :]) > 0, Gh / d[:, :, None] / d[:, None, :], 0.0)
+            G = torch.as_tensor(Gh, device=engine.device)
+        e1, v1 = engine.eigh(G, 0, k)
+        e2, v2 = engine.eigh(G, k, k)
+    else:
         G = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device)
         e1 = e2 = torch.zeros((0, k), dtype=torch.float64, device=engine.device)
         v1 = v2 = torch.zeros((0, k, k), dtype=torch.float64, device=engine.device)
-    else:
-        e1, v1 = engine.eigh(G, 0, k)
-        e2, v2 = engine.eigh(G, k, k)
     G12 = G[:, :k, k:2 * k].contiguous()
     (e1, v1, e2, v2, G12), _ = dist.exchange([e1, v1, e2, v2, G12], [], S)
     e1, v1, e2, v2, G12 = (t.cpu().numpy() for t in (e1, v1, e2, v2, G12))
@@ -115,25 +210,36 @@ def _inv(s):
         return np.where(s > 0, 1.0 / s, 0.0)
 
 
-def _prepare(pls_alg, matrix, cond_order, num_split, mctype, engine):
-    if pls_alg != "mct":
+def _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine):
+    if pls_alg not in ("mct", "rb", "mb"):
         raise exceptions.NotImplementedError(f"split-half for {pls_alg} is not available yet")
     cond_order = np.asarray(cond_order)
     n, p = matrix.shape
     engine = engine if engine is not None else ProjectionEngine(matrix)
-    real, null, g1, g2 = _draw_splits(cond_order, num_split, n, task=True)
-    rows_r, k = _mct_items(cond_order, mctype, n, real, g1, g2)
-    rows_0, _ = _mct_items(cond_order, mctype, n, null, g1, g2)
+    rank, nranks = dist.world()
+    drawn = [None]
+    if rank == 0:       # one RNG stream (rank 0's), like every other phase
+        drawn = [_draw_splits(pls_alg, cond_order, num_split, n, list(bscan) if bscan is not None else None)]
+    if nranks > 1:
+        import torch.distributed as td
+        td.broadcast_object_list(drawn, src=0)
+    splits, g1, g2 = drawn[0]
+    if pls_alg == "mct":
+        rows, gather, k = _items_mct(cond_order, mctype, n, splits, g1, g2)
+    elif pls_alg == "rb":
+        rows, gather, k = _items_rb(cond_order, Y, splits, g1, g2)
+    else:
+        rows, gather, k = _items_mb(cond_order, mctype, Y, list(bscan), splits, g1, g2)
     if p < k:
         raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
-    return engine, np.concatenate((rows_r, rows_0)), k
+    return engine, rows, gather, k
 
 
 def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts=None,
                           bscan=None, Xbscan=None, Ybscan=None, engine=None):
     """split_half_resampling.py:23-401."""
-    engine, rows, k = _prepare(pls_alg, matrix, cond_order, num_split, mctype, engine)
-    U1, s1, _, _, G12 = _decompose(engine, rows, k)
+    engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
+    U1, s1, _, _, G12 = _decompose(engine, rows, gather, k, pls_alg == "mb")
     train = np.repeat(s1[:, None, :], k, axis=1)                       # :195 (row broadcast, Q11)
     test = _inv(s1)[:, :, None] * np.einsum("sji,sjl,slm->sim", U1, G12, U1)    # :196
     S = num_split
@@ -156,8 +262,8 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
 def split_half(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts=None, bscan=None,
                Xbscan=None, Ybscan=None, lv=1, CI=0.95, engine=None):
     """split_half_resampling.py:404-861."""
-    engine, rows, k = _prepare(pls_alg, matrix, cond_order, num_split, mctype, engine)
-    U1, s1, U2, s2, G12 = _decompose(engine, rows, k)
+    engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
+    U1, s1, U2, s2, G12 = _decompose(engine, rows, gather, k, pls_alg == "mb")
     u_rep = (_inv(s1)[:, :, None] * np.einsum("sji,sjl,slm->sim", U1, G12, U2)) * _inv(s2)[:, None, :]   # :682
     v_rep = np.einsum("sji,sjm->sim", U1, U2)                                                             # :683
     S = num_split

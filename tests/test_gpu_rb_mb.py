@@ -1,0 +1,166 @@
+"""GPU parity for behaviour (rb) and multiblock (mb) PLS: the gather + z-score
+kernel (K3), observed decomposition, permutation test and split-half tests
+against the golden vectors from the reference and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import plspy_oracle as orc
+from tests._util import assert_close, load_golden, nonnull
+
+pytestmark = pytest.mark.gpu
+
+
+def _align(mine, ref, live):
+    return np.sign(np.sum(mine[:, live] * ref[:, live], axis=0))
+
+
+@pytest.mark.parametrize("n,p,cells", [(22, 130, [0, 6, 11, 17, 22]), (9, 1, [0, 2, 9]), (40, 257, [0, 40])])
+def test_gather_zscore_matches_oracle(n, p, cells):
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(n)
+    X = rs.randn(n, p) * 3 + 50.0          # large mean / small spread: cancellation check
+    X[:, p // 2] = 7.0                      # a constant voxel -> 0 after z-scoring
+    eng = ProjectionEngine(X)
+    src = np.stack([rs.randint(0, n, n), np.arange(n), rs.permutation(n)])
+    cell_z = np.ones(len(cells) - 1, dtype=int)
+    cell_z[0] = 0 if len(cells) > 2 else 1
+    out = eng.gather_zscore(src, cells, cell_z).cpu().numpy()
+    for it in range(3):
+        G = X[src[it]]
+        for c in range(len(cells) - 1):
+            lo, hi = cells[c], cells[c + 1]
+            if cell_z[c]:
+                ref = orc._zscore_cell(G[lo:hi]) / np.sqrt(hi - lo)
+                ref = np.nan_to_num(ref)
+                # duplicated rows can make a voxel constant inside a cell
+                np.testing.assert_allclose(out[it, lo:hi], ref, rtol=1e-10, atol=1e-12)
+            else:
+                np.testing.assert_array_equal(out[it, lo:hi], G[lo:hi])
+
+
+@pytest.mark.parametrize("name", ["rb_g6x5_c2_b3", "rb_split_g6x6_c2_b2"])
+def test_rb_observed_and_perm(name):
+    import plspy_amd
+    fx = load_golden(name)
+    np.random.seed(fx["seed"])
+    res = plspy_amd.PLS(fx["X"].copy(), fx["groups"], fx["ncond"], Y=fx["Y"].copy(),
+                        num_perm=fx["nperm"], num_boot=0, pls_method="rb")
+    live = nonnull(fx)
+    assert_close(res.R, fx["R"], 1e-10, 1e-12, "R")
+    assert_close(res.s[live], fx["s"][live], 1e-10, 0, "s")
+    sign = _align(res.V, fx["U"], live)           # after the swap res.V is the k x k U
+    assert_close(res.V[:, live] * sign, fx["U"][:, live], 1e-7, 1e-9, "U")
+    assert_close(res.U[:, live] * sign, fx["V"][:, live], 1e-7, 1e-9, "V")
+    assert_close(res.lvcorrs[:, live] * sign, fx["lvcorrs"][:, live], 1e-7, 1e-9, "lvcorrs")
+    rt = res.resample_tests
+    assert_close(rt.perm_debug_dict["s_list"][:, live], fx["s_list"][:, live], 1e-9, 1e-11, "s_list")
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(rt.permute_ratio * n1)[live], np.rint(fx["permute_ratio"] * n1)[live])
+    np.testing.assert_array_equal(np.rint(rt.stepdown_ratio * n1)[live], np.rint(fx["stepdown_ratio"] * n1)[live])
+
+
+def test_rb_perm_seam_with_reference_svd():
+    """The resample seam fed the reference's own U/s/V: all k latent variables
+    comparable, counts exact."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    fx = load_golden("rb_g6x5_c2_b3")
+    np.random.seed(fx["seed"])
+    rt = ResampleTest._create("rb", fx["X"], fx["Y"], fx["U"], fx["s"].copy(), fx["V"], fx["cond_order"],
+                              None, nperm=fx["nperm"], nboot=0)
+    assert_close(rt.perm_debug_dict["s_list"], fx["s_list"], 1e-10, 1e-11, "s_list")
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(rt.permute_ratio * n1), np.rint(fx["permute_ratio"] * n1))
+    np.testing.assert_array_equal(np.rint(rt.stepdown_ratio * n1), np.rint(fx["stepdown_ratio"] * n1))
+
+
+@pytest.mark.parametrize("name", ["mb_g6x6_c3_b2", "mb_split_g6x5_c3_b2"])
+def test_mb_observed_and_perm(name):
+    import plspy_amd
+    fx = load_golden(name)
+    np.random.seed(fx["seed"])
+    res = plspy_amd.PLS(fx["X"].copy(), fx["groups"], fx["ncond"], Y=fx["Y"].copy(), mctype=fx["mctype"],
+                        num_perm=fx["nperm"], num_boot=0, pls_method="mb", bscan=fx["bscan"])
+    live = nonnull(fx)
+    assert_close(res.multiblock, fx["multiblock"], 1e-10, 1e-12, "multiblock")
+    assert_close(res.s[live], fx["s"][live], 1e-10, 0, "s")
+    sign = _align(res.V, fx["U"], live)
+    assert_close(res.U[:, live] * sign, fx["V"][:, live], 1e-7, 1e-9, "V")
+    assert_close(res.Tusc[:, live] * sign, fx["Tusc"][:, live], 1e-7, 1e-9, "Tusc")
+    assert_close(res.Busc[:, live] * sign, fx["Busc"][:, live], 1e-7, 1e-9, "Busc")
+    assert_close(res.lvcorrs[:, live] * sign, fx["lvcorrs"][:, live], 1e-7, 1e-9, "lvcorrs")
+    rt = res.resample_tests
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(rt.permute_ratio * n1)[live], np.rint(fx["permute_ratio"] * n1)[live])
+    np.testing.assert_array_equal(np.rint(rt.stepdown_ratio * n1)[live], np.rint(fx["stepdown_ratio"] * n1)[live])
+
+
+def test_mb_perm_against_oracle_values():
+    """s_hat of every multiblock permutation against the oracle on the same
+    draws (the reference does not export them for mb)."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    fx = load_golden("mb_g6x6_c3_b2")
+    co = fx["cond_order"]
+    obs = orc.observed("mb", fx["X"], co, Y=fx["Y"], mctype=fx["mctype"], bscan=fx["bscan"])
+    np.random.seed(fx["seed"])
+    ref = orc.permutation_test("mb", fx["X"], fx["Y"], fx["U"], fx["s"].copy(), fx["V"], co, fx["mctype"],
+                               fx["nperm"], bscan=fx["bscan"], Xbscan=obs["Xbscan"], Ybscan=obs["Ybscan"])
+    np.random.seed(fx["seed"])
+    rt = ResampleTest._create("mb", fx["X"], fx["Y"], fx["U"], fx["s"].copy(), fx["V"], co, fx["mctype"],
+                              nperm=fx["nperm"], nboot=0, bscan=fx["bscan"], Xbscan=obs["Xbscan"],
+                              Ybscan=obs["Ybscan"])
+    assert_close(rt.perm_debug_dict["s_list"], ref["s_list"], 1e-9, 1e-11, "mb s_list")
+    np.testing.assert_array_equal(rt.permute_ratio, ref["permute_ratio"])
+    np.testing.assert_array_equal(rt.stepdown_ratio, ref["stepdown_ratio"])
+
+
+def test_bootstrap_for_rb_fails_loudly():
+    import plspy_amd
+    from plspy_amd import exceptions
+    fx = load_golden("rb_g6x5_c2_b3")
+    with pytest.raises(exceptions.NotImplementedError):
+        plspy_amd.PLS(fx["X"].copy(), fx["groups"], fx["ncond"], Y=fx["Y"].copy(), num_perm=0, num_boot=3,
+                      pls_method="rb")
+
+
+def _replay_rng_until_split(fx):
+    """Consume np.random exactly as the reference's perm + boot loops do."""
+    co = fx["cond_order"]
+    alg = fx["method"]
+    np.random.seed(fx["seed"])
+    obs = orc.observed(alg, fx["X"], co, Y=fx["Y"], mctype=fx["mctype"], bscan=fx["bscan"])
+    kw = dict(bscan=fx["bscan"], Xbscan=obs.get("Xbscan"), Ybscan=obs.get("Ybscan"))
+    import warnings
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        perm = orc.permutation_test(alg, fx["X"], fx["Y"], fx["U"], fx["s"].copy(), fx["V"], co,
+                                    fx["mctype"], fx["nperm"], **kw)
+        orc.bootstrap_test(alg, fx["X"], fx["Y"], fx["U"], perm["s"], fx["V"], co, fx["mctype"], fx["nboot"],
+                           lvcorrs_orig=fx.get("lvcorrs"), Tvsc_orig=np.zeros((co.size, len(fx["s"]))), **kw)
+    return obs
+
+
+@pytest.mark.parametrize("name", ["rb_split_g6x6_c2_b2", "mb_split_g6x5_c3_b2"])
+def test_split_half_rb_mb(name):
+    from plspy_amd import split_half_resampling as sh
+    fx = load_golden(name)
+    obs = _replay_rng_until_split(fx)
+    alg, co, S, lv = fx["method"], fx["cond_order"], fx["num_split"], fx["lv"]
+    kw = dict(mctype=fx["mctype"], bscan=fx["bscan"], Xbscan=obs.get("Xbscan"), Ybscan=obs.get("Ybscan"))
+    tt = sh.split_half_test_train(alg, fx["X"], fx["Y"], co, S, **kw)
+    res = sh.split_half(alg, fx["X"], fx["Y"], co, S, lv=lv, CI=0.95, **kw)
+    # compare the leading latent variables whose singular values are well
+    # separated from the null space in every split
+    ref_train = fx["tt_pls_s_train"]
+    nl = int(np.sum(ref_train[0, :, :].min(axis=1) > 1e-8 * ref_train[0, 0, :].max()))
+    nl = max(lv, min(nl, 4))
+    for key in ("pls_s_train", "pls_s_train_null"):
+        assert_close(tt[key][:, :nl, :], fx["tt_" + key][:, :nl, :], 1e-8, 1e-11, key)
+    d = np.arange(nl)
+    for key in ("pls_s_test", "pls_s_test_null"):
+        assert_close(tt[key][d, d, :], fx["tt_" + key][d, d, :], 1e-6, 1e-9, key + " diag")
+        assert_close(np.abs(tt[key][:nl, :nl, :]), np.abs(fx["tt_" + key][:nl, :nl, :]), 1e-6, 1e-9, key)
+    for key in ("pls_dist_u", "pls_dist_v", "pls_dist_null_u", "pls_dist_null_v"):
+        assert_close(np.abs(res[key][:nl, :nl, :]), np.abs(fx["sh_" + key][:nl, :nl, :]), 1e-6, 1e-9, key)
+    for key, val in res.items():
+        if not key.startswith("pls_dist"):
+            assert_close(np.array(val)[:lv], fx["sh_" + key][:lv], 1e-5, 1e-9, key)
