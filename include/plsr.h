@@ -172,6 +172,26 @@ int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, const int32_t 
                        void *stream);
 
 /*
+ * ---- host: bit-exact NumPy legacy RandomState draws -------------------------
+ * (no GPU involved; these run wherever the library loads).  key[624] / *pos are
+ * np.random.get_state()[1:3]; they come back advanced so that
+ * np.random.set_state() continues the reference's stream.  Replace the Python
+ * loops around np.random.permutation / np.random.choice in
+ * resample.py:44-77, :125-160 and split_half_resampling.py:136,271,282,316.
+ *   table : [nsub][nc] int32 row ids (subjects x conditions, groups stacked)
+ */
+/* `count` draws of np.random.permutation(n) -> out[count][n] */
+int plsr_rng_permutation(uint32_t *key, int32_t *pos, int32_t n, int32_t count, int32_t *out);
+/* `count` task-PLS permutations (resample.py:63-73) -> out[count][nsub*nc] */
+int plsr_rng_task_permutations(uint32_t *key, int32_t *pos, const int32_t *table, int32_t nsub,
+                               int32_t nc, int32_t count, int32_t *out);
+/* `count` bootstrap samples (resample.py:132-160) -> out[count][nsub*nc];
+ * group_subjects[g] = subjects in group g */
+int plsr_rng_bootstraps(uint32_t *key, int32_t *pos, const int32_t *table,
+                        const int32_t *group_subjects, int32_t ngroups, int32_t nc, int32_t count,
+                        int32_t *out);
+
+/*
  * Kernel timing for the roofline report (bench.py).  When enabled, every
  * projection-kernel launch made by plsr_perm_batch / plsr_boot_batch is
  * bracketed by hipEvents recorded on the launch stream.  plsr_timing_collect

@@ -9,7 +9,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libplsr_hip.so")
-SOURCES = ["plsr_abi.hip"]
+SOURCES = ["plsr_abi.hip", "plsr_rng.cpp"]
 HEADERS = ["plsr_project.hip.h", os.path.join("..", "..", "include", "plsr.h")]
 ARCH = "gfx950"
 
