@@ -10,7 +10,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libplsr_hip.so")
 SOURCES = ["plsr_abi.hip", "plsr_rng.cpp"]
-HEADERS = ["plsr_project.hip.h", os.path.join("..", "..", "include", "plsr.h")]
+HEADERS = ["plsr_project.hip.h", os.path.join("..", "..", "include", "plsr.h")]  # + every *.h in csrc (see _stale)
 ARCH = "gfx950"
 
 

@@ -19,9 +19,11 @@ boot_ratios, boot_debug_dict, ...).  What differs is how the numbers are made:
 
 Random draws replicate the reference's np.random call order (resample.py).
 
-Round-1 coverage: permutation test for mct, rb, mb; bootstrap test for mct.
-The rb / mb bootstrap (per-resample z-scoring of resampled rows) raises
-NotImplementedError -- it does not fall back to a CPU path."""
+Coverage: permutation and bootstrap tests for mct, rb and mb.  In the rb / mb
+bootstrap every resample z-scores its own resampled rows, so each resample
+gets its own gathered matrix (K3) and runs through the item kernels (K4 / K5).
+Contrast variants (cst / csb / cmb) raise NotImplementedError; nothing falls
+back to a CPU path."""
 import abc
 
 import numpy as np
@@ -113,12 +115,15 @@ class _ResampleTestPLS(ResampleTest):
             self.permute_ratio = "NA"
             self.stepdown_ratio = "NA"
         if nboot > 0:
-            if self.pls_alg != "mct":
-                raise exceptions.NotImplementedError(
-                    f"the {self._pls_types[self.pls_alg]} bootstrap is not available on the GPU "
-                    "engine yet (pass num_boot=0); there is no CPU fallback")
-            (self.conf_ints, self.std_errs, self.boot_ratios,
-             self.boot_debug_dict) = self._bootstrap_test(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
+            if self.pls_alg == "mct":
+                (self.conf_ints, self.std_errs, self.boot_ratios,
+                 self.boot_debug_dict) = self._bootstrap_test(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
+            elif self.pls_alg == "rb":           # :185-209
+                (self.conf_ints, self.std_errs, self.boot_ratios, self.LVcorr,
+                 self.boot_debug_dict) = self._boot_rb(U, s, V, nboot, lvcorrs_orig, CI)
+            else:                                # :210-237
+                (self.conf_ints, self.conf_ints_T, self.std_errs, self.boot_ratios, self.LVcorr,
+                 self.boot_debug_dict) = self._boot_mb(U, s, V, nboot, lvcorrs_orig, Tvsc_orig, CI)
         else:                                   # :261-263
             self.conf_ints = ["NA", "NA"]
             self.std_errs = "NA"
@@ -326,6 +331,150 @@ class _ResampleTestPLS(ResampleTest):
             "Tdistrib": Tdistrib,
         }
         return conf_int, std_errs, boot_ratios, debug
+
+    # ------------------------------------------------------------------
+    # bootstrap tests (rb, mb): every resample z-scores its own rows
+    # ------------------------------------------------------------------
+    def _draw_boot_with_guard(self, niter, Ysrc, multiblock):
+        """Bootstrap index vectors with the reference's degenerate-Y redraw
+        (:542-572): up to 100 draws per iteration while any group std of the
+        resampled Y is 0 (guard on the full cond_order, quirk Q8).  rb: one draw
+        per try; mb: task draw then bscan draw per try (:547-553, quirk Q7)."""
+        co = self._cond_order
+        tables = resample.subject_tables(co)
+        n = int(co.sum())
+        if not multiblock:
+            out = np.empty((niter, n), dtype=np.int32)
+        else:
+            btables = resample.subject_tables(co[:, list(self._bscan)])
+            out = np.empty((niter, n + Ysrc.shape[0]), dtype=np.int32)
+        for i in range(niter):
+            for _ in range(100):
+                if multiblock:
+                    ti = resample.draw_bootstrap(tables)                       # :547
+                    bi = resample.draw_bootstrap(btables)                      # :551
+                    row = np.concatenate((ti, bi))
+                else:
+                    bi = resample.draw_bootstrap(tables)                       # :557
+                    row = bi
+                if not (cf.group_stds(Ysrc[bi], co) == 0).any():               # :563-564
+                    break
+            else:
+                raise Exception(_DEGENERATE)                                   # :572
+            out[i] = row
+        return out
+
+    def _finish_items(self, res, niter, ref):
+        """Exchange a sharded boot_items result and form std_errs / boot_ratios."""
+        eng = self._engine
+        (Zt, nsq), (S1, S2) = dist.exchange([res["Zt"], res["nsq"]], [res["S1"], res["S2"]], niter)
+        sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)                  # :695, :701
+        Z = np.transpose(Zt.cpu().numpy(), (0, 2, 1))                          # R x n x k  = X @ VS_b
+        norms = np.sqrt(nsq.cpu().numpy())                                     # R x k
+        with np.errstate(divide="ignore", invalid="ignore"):
+            Zn = np.where(norms[:, None, :] != 0, Z / norms[:, None, :], 0.0)  # X @ normalize(VS_b)  (:623)
+        return sd.cpu().numpy(), ratio.cpu().numpy(), Zn
+
+    def _boot_rb(self, U, s, V, niter, lvcorrs_orig, CI):
+        """bootstrap_permutation.py:467-766 for rb."""
+        eng = self._engine
+        co = self._cond_order
+        Y = np.asarray(self._Y, dtype=float)
+        U = np.asarray(U, dtype=float)
+        V = np.asarray(V, dtype=float)
+        n, b = Y.shape
+        k = U.shape[1]
+        bounds = cf.cell_bounds(co)
+        inds = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Y, False))
+        rank, nranks = dist.world()
+        lo, hi = dist.shard_bounds(niter, rank, nranks)
+        mine = inds[lo:hi]
+        ref = V * s
+
+        def ops_fn(a, z, _):
+            # op_b[j, i] = sum_beh Yz_b[i, beh] U[(cell(i), beh), j]:  VS_b = R_b^T U with
+            # R_b = Yz_b^T Xz_b per cell (class_functions.py:240-242, :620)
+            Yz = cf.zscore_cells(Y[mine[a:z]], bounds)
+            ops = np.empty((z - a, k, n))
+            for c, (l, h) in enumerate(zip(bounds[:-1], bounds[1:])):
+                ops[:, :, l:h] = np.einsum("rib,bj->rji", Yz[:, l:h], U[c * b:(c + 1) * b])
+            return ops
+
+        res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref)
+        std_errs, boot_ratios, Zn = self._finish_items(res, niter, ref)
+        # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
+        L = np.take_along_axis(Zn, inds[:, :, None].astype(np.int64), axis=1)
+        LVcorr = cf.corr_rows(L, cf.zscore_cells(Y[inds], bounds), bounds)
+        z = norm.ppf(1 - (1 - CI) / 2)
+        half = np.std(LVcorr, axis=0) * z                                      # :723-724
+        conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :725
+        debug = {"left_sv_sampled": LVcorr, "right_sv_sampled": None, "indices": inds}
+        return conf_int, std_errs, boot_ratios, LVcorr, debug
+
+    def _boot_mb(self, U, s, V, niter, lvcorrs_orig, Tvsc_orig, CI):
+        """bootstrap_permutation.py:467-766 for mb."""
+        eng = self._engine
+        co = self._cond_order
+        bscan = list(self._bscan)
+        Yb = np.asarray(self._Ybscan, dtype=float)
+        U = np.asarray(U, dtype=float)
+        V = np.asarray(V, dtype=float)
+        ng, nc = co.shape
+        n = int(co.sum())
+        nb, b = Yb.shape
+        nbs = len(bscan)
+        per = nc + nbs * b
+        k = U.shape[1]
+        bounds_b = cf.cell_bounds(co[:, bscan])
+        brows = np.flatnonzero(cf.bscan_mask(co, bscan))                       # bscan index -> row of X
+        draws = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Yb, True))
+        ti, bi = draws[:, :n], draws[:, n:]
+        rank, nranks = dist.world()
+        lo, hi = dist.shard_bounds(niter, rank, nranks)
+        ref = V * s
+        # item matrix = [X[ti] (raw) ; X[brows[bi]] z-scored within the bscan cells]
+        src = np.concatenate((ti, brows[bi]), axis=1)[lo:hi]
+        cell_lo = np.concatenate(([0, n], n + bounds_b[1:]))
+        cell_z = np.ones(len(cell_lo) - 1, dtype=np.int32)
+        cell_z[0] = 0
+        W = self._W
+
+        def raw_rows(a, z):
+            """un-normalised multiblock rows (class_functions.py:479-511) as operators on
+            the item matrix: task rows W on the gathered rows, behaviour rows Yz_b."""
+            Yz = cf.zscore_cells(Yb[bi[lo:hi][a:z]], bounds_b)
+            A = np.zeros((z - a, k, n + nb))
+            for g in range(ng):
+                A[:, g * per:g * per + nc, :n] = W[g * nc:(g + 1) * nc]
+                for ci in range(nbs):
+                    l, h = bounds_b[g * nbs + ci], bounds_b[g * nbs + ci + 1]
+                    r0 = g * per + nc + ci * b
+                    A[:, r0:r0 + b, n + l:n + h] = np.transpose(Yz[:, l:h], (0, 2, 1))
+            return A
+
+        def ops_fn(a, z, rownorm):
+            # rows normalised over all voxels (:503-505) then projected on U (:620):
+            # op_b = U^T D_b^-1 A_b
+            A = raw_rows(a, z)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                scaled = U[None] / rownorm[:, :, None]
+            return np.einsum("rkj,rki->rji", scaled, A)
+
+        res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n)
+        std_errs, boot_ratios, Zn = self._finish_items(res, niter, ref)
+        # behaviour latents (:647-650): Xbscan_new @ V_hat = (X @ V_hat)[brows[bi]]
+        Lb = np.take_along_axis(Zn, brows[bi][:, :, None].astype(np.int64), axis=1)
+        LVcorr = cf.corr_rows(Lb, cf.zscore_cells(Yb[bi], bounds_b), bounds_b)
+        # task distribution (:654-656): cell means of smeanmat(X_new_T) @ V_hat
+        Lt = np.take_along_axis(Zn, ti[:, :, None].astype(np.int64), axis=1)
+        Tdistrib = cf.cell_means_rows(cf.smeanmat_rows(Lt, co, self._mctype), co)
+        z = norm.ppf(1 - (1 - CI) / 2)
+        half = np.std(LVcorr, axis=0) * z
+        conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :723-725
+        half_t = np.std(Tdistrib, axis=0) * z
+        conf_int_T = (Tvsc_orig - half_t, Tvsc_orig + half_t)                  # :732-734
+        debug = {"left_sv_sampled": LVcorr, "right_sv_sampled": None, "indices": draws, "Tdistrib": Tdistrib}
+        return conf_int, conf_int_T, std_errs, boot_ratios, LVcorr, debug
 
     def __repr__(self):
         stg = "Permutation Test Results\n------------------------\n\n"

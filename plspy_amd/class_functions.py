@@ -101,6 +101,55 @@ def bscan_mask(cond_order, bscan):
     return np.array(mask, dtype=bool)
 
 
+def smeanmat_rows(L, cond_order, mctype):
+    """resample._calculate_smeanmat (resample.py:224-287) on a small matrix.  It
+    is a row operator (subtracts group / condition / grand means of the rows),
+    so smeanmat(X_new) @ V == smeanmat(X_new @ V): the engine applies it to the
+    n x k latent scores instead of the n x p data.  L: (..., n, k)."""
+    cond_order = np.asarray(cond_order)
+    ng, nc = cond_order.shape
+    bounds = cell_bounds(cond_order)
+    gb = np.concatenate(([0], np.cumsum(cond_order.sum(axis=1))))
+    cellmean = np.stack([L[..., lo:hi, :].mean(axis=-2) for lo, hi in zip(bounds[:-1], bounds[1:])], axis=-2)
+    out = np.array(L, dtype=float, copy=True)
+    if mctype == 0:
+        for g in range(ng):
+            out[..., gb[g]:gb[g + 1], :] -= L[..., gb[g]:gb[g + 1], :].mean(axis=-2, keepdims=True)
+    elif mctype == 1:
+        cm = np.stack([cellmean[..., [c + g * nc for g in range(ng)], :].mean(axis=-2) for c in range(nc)], axis=-2)
+        for g in range(ng):
+            for c in range(nc):
+                lo, hi = bounds[g * nc + c], bounds[g * nc + c + 1]
+                out[..., lo:hi, :] -= cm[..., c:c + 1, :]
+    elif mctype == 2:
+        out -= L.mean(axis=-2, keepdims=True)
+    elif mctype == 3:
+        cm = np.stack([cellmean[..., [c + g * nc for g in range(ng)], :].mean(axis=-2) for c in range(nc)], axis=-2)
+        grand = cm.mean(axis=-2, keepdims=True)
+        for g in range(ng):
+            gm = L[..., gb[g]:gb[g + 1], :].mean(axis=-2, keepdims=True)
+            for c in range(nc):
+                lo, hi = bounds[g * nc + c], bounds[g * nc + c + 1]
+                out[..., lo:hi, :] += grand - gm - cm[..., c:c + 1, :]
+    else:
+        raise ValueError("mctype must be 0..3")
+    return out
+
+
+def cell_means_rows(L, cond_order):
+    """group x condition means of the rows of a small matrix (..., n, k)."""
+    bounds = cell_bounds(cond_order)
+    return np.stack([L[..., lo:hi, :].mean(axis=-2) for lo, hi in zip(bounds[:-1], bounds[1:])], axis=-2)
+
+
+def corr_rows(L, Yz, bounds):
+    """Stacked per-cell Yz.T @ zscore(L) for batches: L (R, n, k), Yz (R, n, b)
+    already z-scored -> (R, cells*b, k)  (class_functions.py:185-247 on latents)."""
+    Lz = zscore_cells(L, bounds)
+    return np.concatenate([np.einsum("rib,rik->rbk", Yz[:, lo:hi], Lz[:, lo:hi])
+                           for lo, hi in zip(bounds[:-1], bounds[1:])], axis=1)
+
+
 def split_Tu_Bu(U, n_cond, n_behav, n_groups, n_bscan):
     """class_functions.py:518-578: task / behaviour rows of the multiblock U."""
     per = n_cond + n_bscan * n_behav

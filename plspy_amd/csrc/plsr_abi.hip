@@ -490,3 +490,7 @@ extern "C" int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, con
                      dim3(256), 0, (hipStream_t)stream, a);
   return check_launch();
 }
+
+// K4 / K5 entry points (same translation unit: the shared kernels in
+// plsr_project.hip.h are defined once)
+#include "plsr_item_abi.hip.h"

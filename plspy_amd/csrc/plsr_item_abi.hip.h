@@ -1,0 +1,169 @@
+// extern "C" entry points for K4 (item projection) and K5 (latent scores):
+// the bootstrap of behaviour / multiblock PLS.  See include/plsr.h.
+#include "../../include/plsr.h"
+#include "plsr_item.hip.h"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace plsr;
+
+namespace {
+int launch_ok() { return hipGetLastError() == hipSuccess ? PLSR_OK : PLSR_ELAUNCH; }
+
+struct ItemPlan {
+  int MC, ks, nsplit;
+  int64_t nvt;
+  size_t lds, bytes;
+};
+
+bool item_plan(int32_t n, int32_t k, int32_t items, int64_t p, ItemPlan &pl) {
+  if (n <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
+  pl.MC = (k + 15) / 16;
+  if (pl.MC > 4) return false;
+  const int nk = (n + 3) / 4;
+  // keep a workgroup near 52 KiB of LDS so that three fit a CU
+  pl.ks = std::max(1, std::min(nk, (int)(52 * 1024 / (pl.MC * 512 + 2048))));
+  pl.lds = item_lds_bytes(pl.MC, pl.ks);
+  pl.nvt = (p + TV - 1) / TV;
+  pl.nsplit = 1;
+  double best = 0.0;
+  for (int c = 1; c <= 4 && c <= items; ++c) {
+    const double rounds = (double)pl.nvt * c / 768.0;     // 256 CUs x 3 resident workgroups
+    const double eff = rounds / std::ceil(rounds);
+    if (eff > best + 1e-9) {
+      best = eff;
+      pl.nsplit = c;
+    }
+  }
+  pl.bytes = ((size_t)2 * pl.nsplit * p * k * sizeof(double) + 255) / 256 * 256;
+  return true;
+}
+
+struct LatentPlan {
+  int MC, NI, nchunk, tiles_per_chunk;
+  size_t lds, z_elems, n_elems, bytes;
+};
+
+bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl) {
+  if (n <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
+  pl.MC = (k + 15) / 16;
+  pl.NI = ((n + 15) / 16 + WAVES - 1) / WAVES;
+  if (pl.MC > 4 || pl.NI > 4) return false;
+  pl.lds = latent_lds_bytes(pl.MC, pl.NI);
+  const int64_t nvt = (p + LV_T - 1) / LV_T;
+  int want = (int)std::max<int64_t>(1, (1024 + items - 1) / items);
+  want = (int)std::min<int64_t>(want, nvt);
+  pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
+  pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
+  pl.z_elems = (size_t)pl.nchunk * items * k * n;
+  pl.n_elems = (size_t)pl.nchunk * items * k;
+  pl.bytes = ((pl.z_elems + pl.n_elems) * sizeof(double) + 511) / 256 * 256;
+  return true;
+}
+
+template <int MC>
+int run_item(const ItemArgs &a, const ItemPlan &pl, hipStream_t st) {
+  auto kern = item_project_kernel<MC>;
+  if (pl.lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+    return PLSR_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)pl.nvt, (unsigned)pl.nsplit), dim3(256), pl.lds, st, a);
+  return launch_ok();
+}
+
+template <int MC, int NI>
+int run_latent(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
+  auto kern = latent_kernel<MC, NI>;
+  if (pl.lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+    return PLSR_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.items, (unsigned)pl.nchunk), dim3(256), pl.lds, st, a);
+  return launch_ok();
+}
+}  // namespace
+
+extern "C" size_t plsr_item_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p) {
+  ItemPlan pl;
+  return item_plan(n, k, items, p, pl) ? pl.bytes : 0;
+}
+
+extern "C" int plsr_item_project(const double *d_Z, int64_t z_item_stride, int64_t ldz, int64_t p,
+                                 int32_t n, const double *d_frag, int32_t items, int32_t k,
+                                 const double *d_ref, double *d_S1, double *d_S2, double *d_vst,
+                                 int64_t ldv, void *d_work, size_t work_bytes, void *stream) {
+  if (!d_Z || !d_frag || !d_S1 || !d_S2 || !d_work || ldz < p || (d_vst && ldv < p)) return PLSR_EINVAL;
+  ItemPlan pl;
+  if (!item_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  ItemArgs a;
+  a.Z = d_Z;
+  a.z_item_stride = z_item_stride;
+  a.ldz = ldz;
+  a.p = p;
+  a.n = n;
+  a.nk = (n + 3) / 4;
+  a.ks = pl.ks;
+  a.frag = d_frag;
+  a.items = items;
+  a.k = k;
+  a.ref = d_ref;
+  a.S1 = (double *)d_work;
+  a.S2 = a.S1 + (size_t)pl.nsplit * p * k;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = PLSR_EUNSUPPORTED;
+  switch (pl.MC) {
+    case 1: rc = run_item<1>(a, pl, st); break;
+    case 2: rc = run_item<2>(a, pl, st); break;
+    case 3: rc = run_item<3>(a, pl, st); break;
+    case 4: rc = run_item<4>(a, pl, st); break;
+  }
+  if (rc) return rc;
+  const int64_t cnt = p * k;
+  dim3 g((unsigned)((cnt + 255) / 256));
+  hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S1, (const double *)a.S1, cnt, pl.nsplit);
+  hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S2, (const double *)a.S2, cnt, pl.nsplit);
+  return launch_ok();
+}
+
+extern "C" size_t plsr_latent_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p) {
+  LatentPlan pl;
+  return latent_plan(n, k, items, p, pl) ? pl.bytes : 0;
+}
+
+extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const double *d_vst,
+                           int64_t ldv, int32_t items, int32_t k, double *d_Zt, double *d_nsq,
+                           void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_vst || !d_Zt || !d_nsq || !d_work || ldx < p || ldv < p) return PLSR_EINVAL;
+  LatentPlan pl;
+  if (!latent_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  LatentArgs a;
+  a.X = d_X;
+  a.ldx = ldx;
+  a.p = p;
+  a.n = n;
+  a.k = k;
+  a.items = items;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  a.tiles_per_chunk = pl.tiles_per_chunk;
+  a.Zt_part = (double *)d_work;
+  a.nsq_part = a.Zt_part + pl.z_elems;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = PLSR_EUNSUPPORTED;
+#define PLSR_L(M, N) \
+  if (pl.MC == M && pl.NI == N) rc = run_latent<M, N>(a, pl, st);
+  PLSR_L(1, 1) PLSR_L(1, 2) PLSR_L(1, 3) PLSR_L(1, 4) PLSR_L(2, 1) PLSR_L(2, 2) PLSR_L(2, 3) PLSR_L(2, 4)
+  PLSR_L(3, 1) PLSR_L(3, 2) PLSR_L(3, 3) PLSR_L(3, 4) PLSR_L(4, 1) PLSR_L(4, 2) PLSR_L(4, 3) PLSR_L(4, 4)
+#undef PLSR_L
+  if (rc) return rc;
+  const int64_t EZ = (int64_t)items * k * n, EN = (int64_t)items * k;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EZ + 255) / 256), 1), dim3(256), 0, st,
+                     (const double *)a.Zt_part, d_Zt, EZ, pl.nchunk, pl.nchunk);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
+                     (const double *)a.nsq_part, d_nsq, EN, pl.nchunk, pl.nchunk);
+  return launch_ok();
+}

@@ -218,6 +218,80 @@ class ProjectionEngine:
             len(cell_z), _ptr(out), self.p, _stream()), "plsr_gather_zscore")
         return out
 
+    # -- K4 / K5: bootstrap with per-resample matrices --------------------------
+    def _gram_of_items(self, Z, rows):
+        """Grams (rows_b Z_b)(rows_b Z_b)^T for pre-gathered item matrices Z
+        (cnt, n', p) and operator rows (cnt, m, n')."""
+        cnt, m, n = rows.shape
+        mm = (m + 15) // 16 * 16
+        G = torch.empty((cnt, mm, mm), dtype=torch.float64, device=self.device)
+        d_rows = self.dev(rows)
+        frag = torch.empty(self.lib.plsr_rows_frag_elems(n, m, cnt), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_rows), cnt, m, n, _ptr(frag), _stream()),
+                   "plsr_ops_pack_rows")
+        need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p, Z.stride(0))
+        if need == 0:
+            raise _lib.PlsrError(f"plsr_gram: unsupported shape n={n} m={m}")
+        work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.plsr_gram_batch(_ptr(Z), Z.stride(0), Z.stride(1), self.p, n, _ptr(frag), cnt, m,
+                                            _ptr(G), _ptr(work), need, _stream()), "plsr_gram_batch")
+        return G
+
+    def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None):
+        """Bootstrap phase in which every resample has its own gathered /
+        z-scored matrix (behaviour and multiblock PLS).
+
+        src (R, n') int32 + cell_lo / cell_z : what K3 builds per resample;
+        ops_fn(lo, hi, rownorm) -> (hi-lo, k, n') operator rows with
+            VS_b = ops_b @ Z_b; rownorm is None, or -- when raw_rows_fn is
+            given -- the (hi-lo, m) norms over all voxels of the rows
+            raw_rows_fn(lo, hi) @ Z_b (the multiblock row normalisation);
+        latent_rows: number of leading rows of X used for X @ VS_b (default n).
+        Returns dict(S1, S2 (p x k shifted moment sums), Zt (R, k, n) = (X VS_b)^T,
+        nsq (R, k) = column norms^2 of VS_b)."""
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        R, nz = src.shape
+        n = self.n if latent_rows is None else int(latent_rows)
+        refd = self.dev(ref)
+        S1 = torch.zeros((self.p, k), dtype=torch.float64, device=self.device)
+        S2 = torch.zeros_like(S1)
+        Zt = torch.empty((R, k, n), dtype=torch.float64, device=self.device)
+        nsq = torch.empty((R, k), dtype=torch.float64, device=self.device)
+        per_item = (nz + k) * self.p * 8 + 2 * k * nz * 8
+        step = int(max(1, min(R, (self.work_limit // 2) // per_item)))
+        for lo in range(0, R, step):
+            hi = min(R, lo + step)
+            cnt = hi - lo
+            Z = self.gather_zscore(src[lo:hi], cell_lo, cell_z)                  # (cnt, nz, p)
+            rownorm = None
+            if raw_rows_fn is not None:
+                raw = np.ascontiguousarray(raw_rows_fn(lo, hi), dtype=np.float64)
+                G = self._gram_of_items(Z, raw)
+                m = raw.shape[1]
+                rownorm = np.sqrt(torch.diagonal(G, dim1=1, dim2=2)[:, :m].cpu().numpy())
+            ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
+            d_ops = self.dev(ops)
+            frag = torch.empty(self.lib.plsr_rows_frag_elems(nz, k, cnt), dtype=torch.float64,
+                               device=self.device)
+            _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_ops), cnt, k, nz, _ptr(frag), _stream()),
+                       "plsr_ops_pack_rows")
+            vst = torch.empty((cnt, k, self.p), dtype=torch.float64, device=self.device)
+            need = self.lib.plsr_item_workspace_bytes(nz, k, cnt, self.p)
+            if need == 0:
+                raise _lib.PlsrError(f"plsr_item_project: unsupported shape n={nz} k={k}")
+            work = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.plsr_item_project(_ptr(Z), Z.stride(0), Z.stride(1), self.p, nz, _ptr(frag),
+                                                  cnt, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p,
+                                                  _ptr(work), need, _stream()), "plsr_item_project")
+            need2 = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
+            if need2 == 0:
+                raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
+            work2 = torch.empty(need2, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
+                                            k, _ptr(Zt[lo:hi]), _ptr(nsq[lo:hi]), _ptr(work2), need2,
+                                            _stream()), "plsr_latent")
+        return {"S1": S1, "S2": S2, "Zt": Zt, "nsq": nsq, "R": R}
+
     def eigh(self, G, off, k):
         """Eigen-decomposition of the k x k diagonal block at `off` of every
         matrix in G (S, mm, mm): (evals (S,k) descending, evecs (S,k,k))."""

@@ -113,13 +113,57 @@ def test_mb_perm_against_oracle_values():
     np.testing.assert_array_equal(rt.stepdown_ratio, ref["stepdown_ratio"])
 
 
-def test_bootstrap_for_rb_fails_loudly():
+def _seam(fx, **kw):
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    co = fx["cond_order"]
+    alg = fx["method"]
+    obs = orc.observed(alg, fx["X"], co, Y=fx["Y"], mctype=fx["mctype"], bscan=fx["bscan"])
+    if alg == "rb":
+        extra = dict(lvcorrs_orig=orc.compute_corr(fx["X"] @ fx["V"], fx["Y"], co))
+    else:
+        extra = dict(bscan=fx["bscan"], Xbscan=obs["Xbscan"], Ybscan=obs["Ybscan"],
+                     lvcorrs_orig=orc.compute_corr(obs["Xbscan"] @ fx["V"], obs["Ybscan"], co[:, fx["bscan"]]),
+                     Tvsc_orig=orc.group_condition_means(fx["X"] @ orc.normalize(fx["V"]), co))
+    np.random.seed(fx["seed"])
+    return ResampleTest._create(alg, fx["X"], fx["Y"], fx["U"], fx["s"].copy(), fx["V"], co, fx["mctype"],
+                                nperm=fx["nperm"], nboot=fx["nboot"], **extra, **kw)
+
+
+@pytest.mark.parametrize("name", ["rb_g6x5_c2_b3", "rb_split_g6x6_c2_b2", "mb_g6x6_c3_b2", "mb_split_g6x5_c3_b2"])
+def test_bootstrap_rb_mb_against_reference(name):
+    """Resample seam with the reference's own U/s/V: perm then boot consume the
+    RNG exactly like the reference, every bootstrap statistic is compared."""
+    fx = load_golden(name)
+    rt = _seam(fx)
+    live = nonnull(fx)
+    assert_close(rt.std_errs[:, live], fx["std_errs"][:, live], 1e-9, 1e-13, "std_errs")
+    assert_close(rt.boot_ratios[:, live], fx["boot_ratios"][:, live], 1e-8, 1e-10, "boot_ratios")
+    assert_close(rt.LVcorr[:, :, live], fx["LVcorr"][:, :, live], 1e-8, 1e-11, "LVcorr")
+    assert_close(rt.conf_ints[0][:, live], fx["conf_lo"][:, live], 1e-8, 1e-11, "conf lo")
+    assert_close(rt.conf_ints[1][:, live], fx["conf_hi"][:, live], 1e-8, 1e-11, "conf hi")
+    if fx["method"] == "mb":
+        assert_close(rt.conf_ints_T[0][:, live], fx["confT_lo"][:, live], 1e-8, 1e-11, "confT lo")
+        assert_close(rt.conf_ints_T[1][:, live], fx["confT_hi"][:, live], 1e-8, 1e-11, "confT hi")
+    n1 = fx["nperm"] + 1
+    np.testing.assert_array_equal(np.rint(rt.permute_ratio * n1), np.rint(fx["permute_ratio"] * n1))
+
+
+@pytest.mark.parametrize("name", ["rb_g6x5_c2_b3", "mb_g6x6_c3_b2"])
+def test_full_pls_rb_mb_with_bootstrap(name):
     import plspy_amd
-    from plspy_amd import exceptions
-    fx = load_golden("rb_g6x5_c2_b3")
-    with pytest.raises(exceptions.NotImplementedError):
-        plspy_amd.PLS(fx["X"].copy(), fx["groups"], fx["ncond"], Y=fx["Y"].copy(), num_perm=0, num_boot=3,
-                      pls_method="rb")
+    fx = load_golden(name)
+    np.random.seed(fx["seed"])
+    kw = dict(Y=fx["Y"].copy(), num_perm=fx["nperm"], num_boot=fx["nboot"], pls_method=fx["method"])
+    if fx["method"] == "mb":
+        kw.update(mctype=fx["mctype"], bscan=fx["bscan"])
+    res = plspy_amd.PLS(fx["X"].copy(), fx["groups"], fx["ncond"], **kw)
+    live = nonnull(fx)
+    sign = _align(res.V, fx["U"], live)
+    rt = res.resample_tests
+    assert_close(rt.std_errs[:, live], fx["std_errs"][:, live], 1e-7, 1e-11, "std_errs")
+    assert_close(rt.boot_ratios[:, live] * sign, fx["boot_ratios"][:, live], 1e-6, 1e-9, "boot_ratios")
+    assert_close(rt.conf_ints[0][:, live] * sign, np.where(sign > 0, fx["conf_lo"][:, live], fx["conf_hi"][:, live]),
+                 1e-6, 1e-9, "conf ints (sign aligned)")
 
 
 def _replay_rng_until_split(fx):
