@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: the other BASELINE.json configurations through the public
+``plspy_amd.PLS`` / resample seams (not the driver's bench -- that is bench.py).
+
+  --config 3   rb  X=(120x200000) Y=(120x8)  groups [20,20] x 3, perm + boot
+  --config 4   mb  same data, bscan=[1,2], split-half (splits/s)
+  --config 5   mct X=(240x500000) groups [20]x4 x 3, perm + boot
+  --config 2   mct X=(60x200000) through PLS() end to end (host draws, observed SVD included)
+
+``--count`` sets the number of resamples per loop (BASELINE's full counts are
+2000/2000, 1000 splits, 5000/5000); rates are per second of the resampling
+phase, host index generation and operator construction included.  Prints one
+JSON object per run."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def data(n, p, b=0):
+    X = np.random.RandomState(0).randn(n, p)
+    Y = np.random.RandomState(1).randn(n, b) if b else None
+    return X, Y
+
+
+def timed(fn):
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, required=True)
+    ap.add_argument("--count", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    torch.cuda.set_device(0)
+    import plspy_amd
+    from plspy_amd import split_half_resampling as sh
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    from plspy_amd.engine import ProjectionEngine
+
+    np.random.seed(1234)
+    out = {"config": args.config, "device": torch.cuda.get_device_name(0)}
+    if args.config in (2, 5):
+        n, p, groups = (60, 200_000, [10, 10]) if args.config == 2 else (240, 500_000, [20] * 4)
+        R = args.count or (1000 if args.config == 2 else 5000)
+        X, _ = data(n, p)
+        res, t_all = timed(lambda: plspy_amd.PLS(X, groups, 3, num_perm=R, num_boot=R, pls_method="mct"))
+        out.update(workload=f"mct X={n}x{p}, {R} perm + {R} boot via PLS()", seconds_total=t_all,
+                   resamples_per_s_end_to_end=2 * R / t_all, s=res.s.tolist())
+        # resampling phases alone (observed decomposition excluded)
+        eng = ProjectionEngine(X)
+        U, s, V = res.V, res.s.copy(), res.U
+        co = np.array([[g] * 3 for g in groups])
+        rt, t_rs = timed(lambda: ResampleTest._create("mct", X, None, U, s, V, co, 0, nperm=R, nboot=R,
+                                                      Tvsc_orig=np.zeros((len(s), len(s))), engine=eng))
+        out.update(seconds_resampling=t_rs, resamples_per_s=2 * R / t_rs)
+    elif args.config == 3:
+        R = args.count or 2000
+        X, Y = data(120, 200_000, 8)
+        res, t_obs = timed(lambda: plspy_amd.PLS(X, [20, 20], 3, Y=Y, num_perm=0, num_boot=0, pls_method="rb"))
+        U, s, V = res.V, res.s.copy(), res.U
+        co = np.array([[20] * 3, [20] * 3])
+        eng = ProjectionEngine(X)
+        rt, t_perm = timed(lambda: ResampleTest._create("rb", X, Y, U, s, V, co, None, nperm=R, nboot=0, engine=eng))
+        rt, t_boot = timed(lambda: ResampleTest._create("rb", X, Y, U, s, V, co, None, nperm=0, nboot=R,
+                                                        lvcorrs_orig=res.lvcorrs, engine=eng))
+        out.update(workload=f"rb X=120x200000 Y=120x8 (k=48), {R} perm + {R} boot", seconds_observed=t_obs,
+                   seconds_perm=t_perm, seconds_boot=t_boot, perms_per_s=R / t_perm, boots_per_s=R / t_boot,
+                   resamples_per_s=2 * R / (t_perm + t_boot))
+    elif args.config == 4:
+        S = args.count or 1000
+        X, Y = data(120, 200_000, 8)
+        co = np.array([[20] * 3, [20] * 3])
+        eng = ProjectionEngine(X)
+        kw = dict(mctype=0, bscan=[1, 2], engine=eng)
+        _, t_tt = timed(lambda: sh.split_half_test_train("mb", X, Y, co, S, **kw))
+        _, t_sh = timed(lambda: sh.split_half("mb", X, Y, co, S, lv=2, CI=0.95, **kw))
+        out.update(workload=f"mb X=120x200000 Y=120x8 bscan=[1,2] (k=38), {S} splits (tt + sh, real + null)",
+                   seconds_test_train=t_tt, seconds_split_half=t_sh, splits_per_s=S / (t_tt + t_sh))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -357,8 +357,9 @@ bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, bool per_item_x, 
   g.B = 0;
   for (int i = 0; i < ncand; ++i) {
     if (cand[i] > 1 && (cand[i] > items || per_item_x)) continue;   // items with their own X do not share a tile
-    // operator fragments may take at most 96 KiB; the rest stages rows of X
-    if ((size_t)cand[i] * g.MC * nk * 512 <= 96 * 1024) {
+    // operator fragments of several items sharing a tile may take at most 96 KiB;
+    // a single item may take up to 136 KiB (the rest stages rows of X in chunks)
+    if ((size_t)cand[i] * g.MC * nk * 512 <= (size_t)(cand[i] > 1 ? 96 : 136) * 1024) {
       g.B = cand[i];
       break;
     }

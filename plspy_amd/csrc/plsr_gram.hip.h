@@ -212,15 +212,24 @@ __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t it
   }
   __syncthreads();
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    // convergence: largest |a_pq| / sqrt(a_pp a_qq)
+    // convergence: every off-diagonal entry is either small relative to its two
+    // diagonal entries (1e-15 sqrt(a_pp a_qq)) or below the rounding noise of a
+    // Gram with largest entry dmax (4 eps dmax).  The second clause stops the
+    // sweeps on the null space of a rank-deficient Gram, whose entries are noise
+    // of absolute size ~eps*dmax whatever their tiny diagonal says.
+    double dmax = 0.0;
+    for (int r = lane; r < k; r += 64) dmax = fmax(dmax, fabs(As[r * LD + r]));
+    for (int sft = 32; sft > 0; sft >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, sft));
+    const double noise = 8.9e-16 * dmax;
     double worst = 0.0;
     for (int e = lane; e < k * k; e += 64) {
       const int r = e / k, c = e % k;
       if (r < c) {
-        const double d = sqrt(fabs(As[r * LD + r] * As[c * LD + c]));
         const double o = fabs(As[r * LD + c]);
-        const double rel = d > 0.0 ? o / d : (o > 0.0 ? 1.0 : 0.0);
-        worst = fmax(worst, rel);
+        if (o > noise) {
+          const double d = sqrt(fabs(As[r * LD + r] * As[c * LD + c]));
+          worst = fmax(worst, d > 0.0 ? o / d : 1.0);
+        }
       }
     }
     for (int sft = 32; sft > 0; sft >>= 1) worst = fmax(worst, __shfl_xor(worst, sft));
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t it
         if (q < k) {
           const double apq = As[p * LD + q];
           const double app = As[p * LD + p], aqq = As[q * LD + q];
-          if (fabs(apq) > 1e-300 && fabs(apq) >= 1e-18 * sqrt(fabs(app * aqq))) {
+          if (fabs(apq) > 0.25 * noise && fabs(apq) >= 1e-17 * sqrt(fabs(app * aqq))) {
             const double tau = (aqq - app) / (2.0 * apq);
             const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
             c = 1.0 / sqrt(1.0 + t * t);

@@ -317,7 +317,7 @@ class ProjectionEngine:
         live = lam > tol * max(lam[0], 0.0)
         s = np.sqrt(np.where(live, lam, 0.0))
         cols = (rows.T @ U).T                           # k operator columns: VS = X^T (A^T U)
-        VS = self.boot_phase(k, cols=cols[None], dump=True)["vs"][0].cpu().numpy()   # p x k
+        VS = self.apply_operator(cols).cpu().numpy().T   # p x k, 16 columns per launch
         with np.errstate(divide="ignore", invalid="ignore"):
             V = np.where(live[None, :], VS / s[None, :], 0.0)
         return U, s, V

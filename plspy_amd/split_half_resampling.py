@@ -104,10 +104,12 @@ def _items_mct(cond_order, mctype, n, splits, g1, g2):
     W1 = operators.mean_centre_operator(_get_cond_order((sum(g1) * nc,), tuple(g1), nc), mctype)
     W2 = operators.mean_centre_operator(_get_cond_order((sum(g2) * nc,), tuple(g2), nc), mctype)
     k = W1.shape[0]
-    rows = np.zeros((len(splits), 2 * k, n))
-    for i, d in enumerate(splits):
-        rows[i, :k, d["x1"]] = W1.T          # half-1 row r of the gathered block is X[x1[r]]
-        rows[i, k:, d["x2"]] = W2.T
+    S = len(splits)
+    rows = np.zeros((S, 2 * k, n))
+    ridx = np.arange(S)[:, None]
+    # half-1 row r of the gathered block is X[x1[r]]: column x1[r] of the operator gets W1[:, r]
+    rows[ridx, :k, np.stack([d["x1"] for d in splits])] = W1.T[None]
+    rows[ridx, k:, np.stack([d["x2"] for d in splits])] = W2.T[None]
     return rows, None, k
 
 
@@ -123,12 +125,17 @@ def _items_rb(cond_order, Y, splits, g1, g2):
     n = n1 + int(b2[-1])
     Y = np.asarray(Y, dtype=float)
     k = (len(b1) - 1) * Y.shape[1]
-    rows = np.zeros((len(splits), 2 * k, n))
-    src = np.empty((len(splits), n), dtype=np.int32)
-    for i, d in enumerate(splits):
-        src[i, :n1], src[i, n1:] = d["x1"], d["x2"]
-        rows[i, :k, :n1] = cf.corr_operator(cf.zscore_cells(Y[d["y1"]], b1), b1)
-        rows[i, k:, n1:] = cf.corr_operator(cf.zscore_cells(Y[d["y2"]], b2), b2)
+    S = len(splits)
+    nbeh = Y.shape[1]
+    rows = np.zeros((S, 2 * k, n))
+    src = np.concatenate((np.stack([d["x1"] for d in splits]), np.stack([d["x2"] for d in splits])),
+                         axis=1).astype(np.int32)
+    # all splits at once: z-score the halves' behaviour rows within cells and lay
+    # them out as block-diagonal operator rows
+    for h, (key, bb, coff, roff) in enumerate((("y1", b1, 0, 0), ("y2", b2, n1, k))):
+        Yz = cf.zscore_cells(Y[np.stack([d[key] for d in splits])], bb)          # S x n_h x b
+        for c, (lo, hi) in enumerate(zip(bb[:-1], bb[1:])):
+            rows[:, roff + c * nbeh:roff + (c + 1) * nbeh, coff + lo:coff + hi] = np.transpose(Yz[:, lo:hi], (0, 2, 1))
     cell_lo = np.concatenate((b1, n1 + b2[1:]))
     gather = dict(src=src, cell_lo=cell_lo, cell_z=np.ones(len(cell_lo) - 1, dtype=np.int32))
     return rows, gather, k
@@ -156,17 +163,20 @@ def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2):
     nb1, nb2 = int(halves[0]["bb"][-1]), int(halves[1]["bb"][-1])
     n = n1 + n2
     width = n + nb1 + nb2
-    rows = np.zeros((len(splits), 2 * k, width))
-    src = np.empty((len(splits), width), dtype=np.int32)
-    for i, d in enumerate(splits):
-        src[i] = np.concatenate((d["x1"], d["x2"], d["xb1"], d["xb2"]))
-        for h, (xoff, boff, key) in enumerate(((0, n, "b1"), (n1, n + nb1, "b2"))):
-            hv = halves[h]
-            Ab = cf.corr_operator(cf.zscore_cells(Y[d[key]], hv["bb"]), hv["bb"])
-            for g in range(ng):
-                r0 = h * k + g * per
-                rows[i, r0:r0 + nc, xoff:xoff + hv["n"]] = hv["W"][g * nc:(g + 1) * nc]
-                rows[i, r0 + nc:r0 + per, boff:boff + Ab.shape[1]] = Ab[g * nbs * b:(g + 1) * nbs * b]
+    S = len(splits)
+    rows = np.zeros((S, 2 * k, width))
+    src = np.concatenate([np.stack([d[key] for d in splits]) for key in ("x1", "x2", "xb1", "xb2")],
+                         axis=1).astype(np.int32)
+    for h, (xoff, boff, key) in enumerate(((0, n, "b1"), (n1, n + nb1, "b2"))):
+        hv = halves[h]
+        Yz = cf.zscore_cells(Y[np.stack([d[key] for d in splits])], hv["bb"])     # S x nb_h x b, all splits at once
+        for g in range(ng):
+            r0 = h * k + g * per
+            rows[:, r0:r0 + nc, xoff:xoff + hv["n"]] = hv["W"][g * nc:(g + 1) * nc]
+            for ci in range(nbs):
+                lo, hi = hv["bb"][g * nbs + ci], hv["bb"][g * nbs + ci + 1]
+                rb0 = r0 + nc + ci * b
+                rows[:, rb0:rb0 + b, boff + lo:boff + hi] = np.transpose(Yz[:, lo:hi], (0, 2, 1))
     cell_lo = np.concatenate(([0, n], n + halves[0]["bb"][1:], n + nb1 + halves[1]["bb"][1:]))
     cell_z = np.ones(len(cell_lo) - 1, dtype=np.int32)
     cell_z[0] = 0                                    # the task rows are used raw
@@ -241,7 +251,7 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
     engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
     U1, s1, _, _, G12 = _decompose(engine, rows, gather, k, pls_alg == "mb")
     train = np.repeat(s1[:, None, :], k, axis=1)                       # :195 (row broadcast, Q11)
-    test = _inv(s1)[:, :, None] * np.einsum("sji,sjl,slm->sim", U1, G12, U1)    # :196
+    test = _inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U1)    # :196
     S = num_split
 
     def slab(a):
@@ -264,8 +274,8 @@ def split_half(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts
     """split_half_resampling.py:404-861."""
     engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
     U1, s1, U2, s2, G12 = _decompose(engine, rows, gather, k, pls_alg == "mb")
-    u_rep = (_inv(s1)[:, :, None] * np.einsum("sji,sjl,slm->sim", U1, G12, U2)) * _inv(s2)[:, None, :]   # :682
-    v_rep = np.einsum("sji,sjm->sim", U1, U2)                                                             # :683
+    u_rep = (_inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U2)) * _inv(s2)[:, None, :]   # :682
+    v_rep = np.transpose(U1, (0, 2, 1)) @ U2                                                             # :683
     S = num_split
 
     def slab(a):
