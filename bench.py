@@ -71,8 +71,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # one rank per GPU over RCCL.  PLSR_DIST_BACKEND=gloo is a rehearsal
+        # switch for boxes with fewer GPUs than ranks (ranks then share devices).
+        backend = os.environ.get("PLSR_DIST_BACKEND", "nccl")
+        dev_id = local % torch.cuda.device_count()
+        torch.cuda.set_device(dev_id)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_id}"))
+        else:
+            td.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -138,7 +145,8 @@ def main():
     boot_ms = [ms[i] for i in range(nt) if kind[i] == 1]
     perm_ms = [ms[i] for i in range(nt) if kind[i] == 0]
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64,
+                        device=eng.device if (world == 1 or td.get_backend() == "nccl") else "cpu")
     if world > 1:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
     elapsed = float(tmax.item())

@@ -51,7 +51,10 @@ def exchange(per_resample, summed, R):
     rank, n = world()
     if n == 1:
         return per_resample, summed
-    dev = per_resample[0].device if per_resample else summed[0].device
+    out_dev = per_resample[0].device if per_resample else summed[0].device
+    # RCCL moves device buffers over xGMI directly; any other backend (gloo in
+    # the CPU tests) is staged through host memory
+    dev = out_dev if td.get_backend() == "nccl" else torch.device("cpu")
     bounds = [shard_bounds(R, r, n) for r in range(n)]
     maxrows = max(hi - lo for lo, hi in bounds)
     row_elems = [int(np.prod(t.shape[1:])) for t in per_resample]
@@ -60,10 +63,10 @@ def exchange(per_resample, summed, R):
     send = torch.zeros(width, dtype=torch.float64, device=dev)
     off = 0
     for t, re in zip(per_resample, row_elems):
-        send[off:off + t.numel()] = t.reshape(-1)
+        send[off:off + t.numel()] = t.reshape(-1).to(dev)
         off += maxrows * re
     for t, se in zip(summed, sum_elems):
-        send[off:off + se] = t.reshape(-1)
+        send[off:off + se] = t.reshape(-1).to(dev)
         off += se
     recv = [torch.empty_like(send) for _ in range(n)]
     td.all_gather(recv, send)
@@ -72,13 +75,13 @@ def exchange(per_resample, summed, R):
     for t, re in zip(per_resample, row_elems):
         parts = [recv[r][off:off + (hi - lo) * re].reshape((hi - lo,) + tuple(t.shape[1:]))
                  for r, (lo, hi) in enumerate(bounds)]
-        full.append(torch.cat(parts, dim=0))
+        full.append(torch.cat(parts, dim=0).to(out_dev))
         off += maxrows * re
     sums = []
     for t, se in zip(summed, sum_elems):
         acc = recv[0][off:off + se].clone()
         for r in range(1, n):
             acc += recv[r][off:off + se]
-        sums.append(acc.reshape(t.shape))
+        sums.append(acc.reshape(t.shape).to(out_dev))
         off += se
     return full, sums
