@@ -276,6 +276,22 @@ def run_pls(M):
     return U, s, Vt.T
 
 
+def run_pls_contrast(M, C):
+    """class_functions.py:126-162: U = C, s = row norms of C.T @ M, V = (C.T @ M).T."""
+    CB = C.T @ M
+    return C, np.sqrt(np.sum(CB ** 2, axis=1)), CB.T
+
+
+def cmb_contrast_rows(contrasts, ng, nc, nb, bscan):
+    """pls_classes.py:1788-1799: rows of the user's contrast matrix kept for the
+    multiblock rows (all task conditions, behaviour rows of the bscan conditions)."""
+    Ti = np.ones(nc)
+    Bi = np.zeros((nb, nc))
+    Bi[:, bscan] = 1
+    mask = np.tile(np.concatenate([Ti.reshape(-1, order="F"), Bi.reshape(-1, order="F")]), ng)
+    return contrasts[mask.astype(bool), :]
+
+
 def calculate_smeanmat(Xt, cond_order, mctype):
     """resample.py:224-287: row-level centring of the task bootstrap sample."""
     cond_order = np.asarray(cond_order)
@@ -308,12 +324,45 @@ def bscan_mask(cond_order, bscan):
 # --------------------------------------------------------------------------
 # observed decomposition  (pls_classes.py constructors, numbers only)
 # --------------------------------------------------------------------------
-def observed(pls_alg, X, cond_order, Y=None, mctype=0, bscan=None):
+def observed(pls_alg, X, cond_order, Y=None, mctype=0, bscan=None, contrasts=None):
     """The decomposition each PLS class performs before resampling.
 
-    mct: pls_classes.py:258-266; rb: :570-586; mb: :1430-1489 (subset)."""
+    mct: pls_classes.py:258-266; rb: :570-586; mb: :1430-1489 (subset);
+    cst: :853-865; csb: :1128-1143; cmb: :1788-1857 (subset).  For the contrast
+    variants ``contrasts`` is the user's matrix (normalised here like the
+    classes do) and U is the normalised contrast matrix."""
     cond_order = np.asarray(cond_order)
     out = {}
+    if pls_alg in ("cst", "csb", "cmb"):
+        ng, nc = cond_order.shape
+        if pls_alg == "cst":
+            C = normalize(contrasts)
+            out["R"] = M = group_condition_means(X, cond_order)
+        elif pls_alg == "csb":
+            C = normalize(contrasts)
+            out["R"] = M = compute_corr(X, Y, cond_order)
+        else:
+            C = normalize(cmb_contrast_rows(contrasts, ng, nc, Y.shape[1], bscan))
+            m = bscan_mask(cond_order, bscan)
+            out["Xbscan"], out["Ybscan"] = X[m], Y[m]
+            out["multiblock"] = M = create_multiblock(X, cond_order, "cmb", bscan, mctype,
+                                                      Xbscan=X[m], Ybscan=Y[m])
+        U, s, V = run_pls_contrast(M, C)
+        out["contrasts"] = C
+        out["lvintercorrs"] = V.T @ V
+        if pls_alg == "cst":
+            out["X_latent"] = X @ normalize(V)
+            out["Tvsc_orig"] = group_condition_means(out["X_latent"], cond_order)
+        elif pls_alg == "csb":
+            out["X_latent"] = X @ V
+        else:
+            Tx = X @ normalize(V)
+            Bx = out["Xbscan"] @ V
+            out["Tusc"], out["Busc"] = Tx, Bx
+            out["Tvsc_orig"] = group_condition_means(Tx, cond_order)
+            out["lvcorrs"] = compute_corr(Bx, out["Ybscan"], cond_order[:, bscan])
+        out["U"], out["s"], out["V"] = U, s, V
+        return out
     if pls_alg == "mct":
         out["X_means"], out["X_mc"] = mean_centre(X, cond_order, mctype)
         U, s, V = run_pls(out["X_mc"])
@@ -347,11 +396,12 @@ def observed(pls_alg, X, cond_order, Y=None, mctype=0, bscan=None):
 # --------------------------------------------------------------------------
 def permutation_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
                      bscan=None, Xbscan=None, Ybscan=None, threshold=1e-12,
-                     sampler=None):
+                     sampler=None, contrast=None):
     """Returns dict(permute_ratio, stepdown_ratio, s_list, s (thresholded copy)).
 
     Unlike the reference (Q1) ``s`` is not mutated in place; the thresholded
-    copy is returned."""
+    copy is returned.  ``contrast``: the (normalised) contrast matrix of the
+    cst / csb / cmb variants (:407-410, :429-433)."""
     sampler = sampler or Sampler()
     cond_order = np.asarray(cond_order)
     s = np.array(s, dtype=float)
@@ -359,9 +409,10 @@ def permutation_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
     greater = np.zeros(s.shape)
     step_greater = np.zeros(s.shape)
     s_list = np.empty((niter, s.shape[0]))
+    multi = pls_alg in MULTI_ALGS
 
-    if pls_alg == "mb":                                        # :305-312
-        raw = create_multiblock(X, cond_order, "mb", bscan, mctype, norm_opt=False,
+    if multi:                                                  # :305-312
+        raw = create_multiblock(X, cond_order, pls_alg, bscan, mctype, norm_opt=False,
                                 Xbscan=Xbscan, Ybscan=Ybscan)
         total = np.sum(raw ** 2)
         org_s = np.sqrt(s ** 2 / np.sum(s ** 2) * total)
@@ -373,7 +424,10 @@ def permutation_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
         if pls_alg == "mct":
             inds = sampler.perm_task(cond_order)               # :329
             permuted = mean_centre(X[inds], cond_order, mctype)[1]   # :385
-        elif pls_alg == "rb":
+        elif pls_alg == "cst":
+            inds = sampler.perm_task(cond_order)               # :329
+            permuted = group_condition_means(X[inds], cond_order)    # :389
+        elif pls_alg in BEHAV_ALGS:
             for _ in range(100):                               # :334-353
                 Yn = Y[sampler.perm_rows(Y.shape[0])]          # :338
                 if not (group_stds(Yn, cond_order) == 0).any():
@@ -381,7 +435,7 @@ def permutation_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
             else:
                 raise Exception("degenerate behaviour data")   # :355
             permuted = compute_corr(X, Yn, cond_order)         # :396
-        elif pls_alg == "mb":
+        elif multi:
             for _ in range(100):
                 ti = sampler.perm_task(cond_order)             # :343
                 Yn = Ybscan[sampler.perm_rows(Ybscan.shape[0])]   # :347
@@ -391,10 +445,19 @@ def permutation_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
             else:
                 raise Exception("degenerate behaviour data")
             Xt = X[ti]
-            permuted = create_multiblock(Xt, cond_order, "mb", bscan, mctype,
+            permuted = create_multiblock(Xt, cond_order, pls_alg, bscan, mctype,
                                          Xbscan=Xbscan, Ybscan=Yn)     # :392
         else:
             raise ValueError(pls_alg)
+
+        if contrast is not None:                               # :429-433 (the SVD at :410 is discarded, Q4)
+            cross = normalize(contrast).T @ permuted
+            s_hat = np.sqrt(np.sum(cross ** 2, axis=1))
+            greater += s_hat >= s
+            s_list[i] = s_hat
+            tot_perm = np.array([np.sum(s_hat[r:] ** 2) for r in range(len(s_hat))])
+            step_greater += tot_perm >= tot_org
+            continue
 
         VS = permuted.T @ U                                    # :404
         s_hat = np.sqrt(np.sum(VS ** 2, axis=0))               # :405
@@ -426,18 +489,24 @@ def permutation_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
 # --------------------------------------------------------------------------
 def bootstrap_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
                    bscan=None, Xbscan=None, Ybscan=None, lvcorrs_orig=None,
-                   Tvsc_orig=None, CI=0.95, sampler=None, keep_right=True):
+                   Tvsc_orig=None, CI=0.95, sampler=None, keep_right=True, contrast=None):
+    """``contrast``: the (normalised) contrast matrix of cst / csb / cmb
+    (:658-675, :703).  For csb the reference's last step subtracts a
+    (cells*b x q) array from the q x q ``lvcorrs_orig`` it is handed
+    (pls_classes.py:1158) and raises a broadcasting ValueError; so does this."""
     sampler = sampler or Sampler()
     cond_order = np.asarray(cond_order)
     k = U.shape[1]
+    multi = pls_alg in MULTI_ALGS
     right = np.empty((niter, V.shape[0], k))                   # :497
     left = None
     Tdist = None
     LVcorr = None
+    bco = cond_order[:, bscan] if bscan is not None else cond_order    # csb: bscan is None (Q20)
     for i in range(niter):
         Yn = None
         for _ in range(100):                                   # :543-570
-            if pls_alg == "mb":
+            if multi:
                 ti = sampler.boot(cond_order)                  # :547
                 bi = sampler.boot(cond_order[:, bscan])        # :551
                 Xt, Xn, Yn = X[ti], Xbscan[bi], Ybscan[bi]
@@ -453,10 +522,12 @@ def bootstrap_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
 
         if pls_alg == "mct":
             permuted = mean_centre(Xn, cond_order, mctype)[1]  # :603
-        elif pls_alg == "rb":
+        elif pls_alg == "cst":
+            permuted = group_condition_means(Xn, cond_order)   # :607
+        elif pls_alg in BEHAV_ALGS:
             permuted = compute_corr(Xn, Yn, cond_order)        # :613
         else:
-            permuted = create_multiblock(Xt, cond_order, "mb", bscan, mctype,
+            permuted = create_multiblock(Xt, cond_order, pls_alg, bscan, mctype,
                                          Xbscan=Xn, Ybscan=Yn)   # :610
 
         U_hat = (V.T @ permuted.T).T                           # :617
@@ -475,7 +546,7 @@ def bootstrap_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
             if LVcorr is None:
                 LVcorr = np.empty((niter,) + lc.shape)
             LVcorr[i] = lc
-        else:                                                  # :644-656
+        elif pls_alg == "mb":                                  # :644-656
             lc = compute_corr(Xn @ V_hat, Yn, cond_order[:, bscan])
             if LVcorr is None:
                 LVcorr = np.empty((niter,) + lc.shape)
@@ -483,13 +554,25 @@ def bootstrap_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
             LVcorr[i] = lc
             sm = calculate_smeanmat(Xt, cond_order, mctype)
             Tdist[i] = group_condition_means(sm @ V_hat, cond_order)
+        if contrast is not None:                               # :658-675
+            cross = normalize(contrast).T @ permuted
+            ncb = normalize(cross.T)
+            if pls_alg in ("cmb", "cst"):
+                if Tdist is None:
+                    Tdist = np.empty((niter, cond_order.size, k))
+                Tdist[i] = group_condition_means(X @ ncb, cond_order)   # :665-666
+            if pls_alg in ("cmb", "csb"):
+                lc = compute_corr(Xn @ ncb, Yn, bco)           # :671-674
+                if LVcorr is None:
+                    LVcorr = np.empty((niter,) + lc.shape)
+                LVcorr[i] = lc
 
     std_errs = np.std(right, axis=0)                           # :695
     with np.errstate(divide="ignore", invalid="ignore"):
-        boot_ratios = (V * s) / std_errs                       # :701
+        boot_ratios = (V * s) / std_errs if contrast is None else V / std_errs   # :700-703
     z = _norm.ppf(1 - (1 - CI) / 2)                            # :709
     out = {"std_errs": std_errs, "boot_ratios": boot_ratios}
-    if pls_alg == "mct":                                       # :711-717
+    if pls_alg in TASK_ALGS:                                   # :711-717
         half = np.std(Tdist, axis=0) * z
         out["conf_ints"] = (Tvsc_orig - half, Tvsc_orig + half)
         out["left_sv_sampled"] = left
@@ -499,7 +582,7 @@ def bootstrap_test(pls_alg, X, Y, U, s, V, cond_order, mctype, niter,
         out["conf_ints"] = (lvcorrs_orig - half, lvcorrs_orig + half)
         out["LVcorr"] = LVcorr
         out["left_sv_sampled"] = LVcorr
-        if pls_alg == "mb":
+        if multi:
             half = np.std(Tdist, axis=0) * z
             out["conf_ints_T"] = (Tvsc_orig - half, Tvsc_orig + half)
             out["Tdistrib"] = Tdist
@@ -515,8 +598,10 @@ def _cond_order_for(groups, nc):
     return np.array([[g] * nc for g in groups])
 
 
-def _split_dim(pls_alg, p, cond_order, Y, bscan, Ybscan):
+def _split_dim(pls_alg, p, cond_order, Y, bscan, Ybscan, contrasts=None):
     ng, nc = np.asarray(cond_order).shape
+    if contrasts is not None:
+        return min(p, contrasts.shape[1])                      # :84
     if pls_alg == "mct":
         return min(p, nc * ng)                                 # :80
     if pls_alg == "mb":
@@ -545,39 +630,45 @@ def _draw_split(sampler, tables, nc, bscan):
 def _half_block(pls_alg, X1, Y1, co1, mctype, bscan, Xb1, Yb1):
     if pls_alg == "mct":
         return mean_centre(X1, co1, mctype)[1]                 # :186
-    if pls_alg == "rb":
-        return compute_corr(X1, Y1, co1)                       # :203
-    return create_multiblock(X1, co1, "mb", bscan, mctype, Xbscan=Xb1, Ybscan=Yb1)   # :245
+    if pls_alg == "cst":
+        return group_condition_means(X1, co1)                  # :212
+    if pls_alg in BEHAV_ALGS:
+        return compute_corr(X1, Y1, co1)                       # :203, :228
+    return create_multiblock(X1, co1, pls_alg, bscan, mctype, Xbscan=Xb1, Ybscan=Yb1)   # :245
 
 
 def split_half_both(pls_alg, matrix, Y, cond_order, num_split, mctype=None,
                     bscan=None, Ybscan=None, lv=1, CI=0.95, which="tt",
-                    sampler=None):
+                    sampler=None, contrasts=None):
     """``which="tt"`` -> split_half_test_train (:23-401);
     ``which="sh"`` -> split_half (:404-861).  Same splitting code in both."""
     sampler = sampler or Sampler()
     cond_order = np.asarray(cond_order)
     n, p = matrix.shape
     ng, nc = cond_order.shape
-    d = _split_dim(pls_alg, p, cond_order, Y, bscan, Ybscan)
+    d = _split_dim(pls_alg, p, cond_order, Y, bscan, Ybscan, contrasts)
+
+    def decomp(M):
+        return run_pls(M) if contrasts is None else run_pls_contrast(M, contrasts)   # :194 / :216
     A = np.zeros((d, d, num_split))
     B = np.zeros((d, d, num_split))
     A0 = np.zeros((d, d, num_split))
     B0 = np.zeros((d, d, num_split))
     tables = subject_table(cond_order)
     alltab = np.concatenate(tables)
-    multi = pls_alg == "mb"
+    multi = pls_alg in MULTI_ALGS
+    behav = pls_alg in BEHAV_ALGS
     g1 = g2 = None
 
     def decompose(i, X1, X2, Y1, Y2, Xb1, Yb1, Xb2, Yb2, co1, co2, outA, outB):
         M1 = _half_block(pls_alg, X1, Y1, co1, mctype, bscan, Xb1, Yb1)
         M2 = _half_block(pls_alg, X2, Y2, co2, mctype, bscan, Xb2, Yb2)
-        U1, s1, V1 = run_pls(M1)
+        U1, s1, V1 = decomp(M1)
         if which == "tt":
             outA[:, :, i] = s1                                 # :195 (Q11 broadcast)
             outB[:, :, i] = V1.T @ M2.T @ U1                   # :196
         else:
-            U2, _, V2 = run_pls(M2)
+            U2, _, V2 = decomp(M2)
             outA[:, :, i] = V1.T @ V2                          # :682
             outB[:, :, i] = U1.T @ U2                          # :683
 
@@ -586,7 +677,7 @@ def split_half_both(pls_alg, matrix, Y, cond_order, num_split, mctype=None,
         co1, co2 = _cond_order_for(g1, nc), _cond_order_for(g2, nc)
         X1, X2 = matrix[i1], matrix[i2]
         Y1 = Y2 = Xb1 = Xb2 = Yb1 = Yb2 = None
-        if pls_alg == "rb":
+        if behav:
             Y1, Y2 = Y[i1], Y[i2]
         if multi:
             Xb1, Yb1 = matrix[bs[0]], Y[bs[0]]
@@ -603,14 +694,14 @@ def split_half_both(pls_alg, matrix, Y, cond_order, num_split, mctype=None,
         i1, i2 = t[:half, :].flatten(), t[half:, :].flatten()
         if multi:
             b1, b2 = t[:half][:, bscan].flatten(), t[half:][:, bscan].flatten()
-        if pls_alg in ("mct", "mb"):
+        if pls_alg in ("mct", "cst", "mb", "cmb"):
             permx = matrix[sampler.perm_rows(n)]               # :282
         else:
             permx = matrix
         X1, X2 = permx[i1], permx[i2]
         Y1 = Y2 = Xb1 = Xb2 = Yb1 = Yb2 = None
-        if pls_alg == "rb":
-            permy = Y[sampler.perm_rows(n)]                    # :316
+        if behav:
+            permy = Y[sampler.perm_rows(n)]                    # :316, :340
             Y1, Y2 = permy[i1], permy[i2]
         if multi:
             Xb1, Yb1 = permx[b1], Y[b1]                        # :358

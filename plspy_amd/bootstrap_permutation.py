@@ -85,6 +85,9 @@ _DEGENERATE = ("Please check your behaviour data, and make sure that none of the
 @ResampleTest._register_subclass("mct")
 @ResampleTest._register_subclass("rb")
 @ResampleTest._register_subclass("mb")
+@ResampleTest._register_subclass("cst")
+@ResampleTest._register_subclass("csb")
+@ResampleTest._register_subclass("cmb")
 class _ResampleTestPLS(ResampleTest):
     def __init__(self, X, Y, U, s, V, cond_order, mctype, contrast=None, preprocess=None,
                  nperm=1000, nboot=1000, bscan=None, Xbscan=None, Ybscan=None,
@@ -92,14 +95,18 @@ class _ResampleTestPLS(ResampleTest):
                  _pls_alg=None):
         self.pls_alg = _pls_alg or self.pls_alg
         self.CI = CI
-        if contrast is not None:
-            raise exceptions.NotImplementedError("contrast variants are not available yet")
         self._cond_order = np.asarray(cond_order)
         self._mctype = mctype
         self._engine = engine if engine is not None else ProjectionEngine(X)
         self._X, self._Y = X, Y
         self._bscan, self._Ybscan = bscan, Ybscan
         n = self._engine.n
+        task, behav, multi = self.pls_alg in ("mct", "cst"), self.pls_alg in ("rb", "csb"), self.pls_alg in ("mb", "cmb")
+        if (self.pls_alg in ("cst", "csb", "cmb")) != (contrast is not None):
+            raise exceptions.MissingParameterError("contrast variants need a contrast matrix (and only they take one)")
+        # contrast variants project on the (normalised) contrast matrix instead of
+        # the observed U (:429-431, :659-660) and skip the s_hat threshold
+        self._C = None if contrast is None else cf.normalize(np.asarray(contrast, dtype=float))
         if self.pls_alg in ("mct", "mb"):
             if preprocess is not None and self.pls_alg == "mct":
                 # a linear preprocess with the reference's signature: its operator
@@ -107,20 +114,33 @@ class _ResampleTestPLS(ResampleTest):
                 self._W = operators.operator_from_callable(preprocess, n, self._cond_order, mctype)
             else:
                 self._W = operators.mean_centre_operator(self._cond_order, mctype)
+        elif self.pls_alg in ("cst", "cmb"):
+            # the contrast variants use the plain cell means as task block (:389, class_functions.py:482)
+            self._W = operators.cell_mean_operator(self._cond_order)
 
         if nperm > 0:
-            perm = {"mct": self._perm_mct, "rb": self._perm_rb, "mb": self._perm_mb}[self.pls_alg]
+            perm = self._perm_mct if task else (self._perm_rb if behav else self._perm_mb)
             self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = perm(U, s, nperm)
         else:                                   # bootstrap_permutation.py:181-182
             self.permute_ratio = "NA"
             self.stepdown_ratio = "NA"
         if nboot > 0:
-            if self.pls_alg == "mct":
+            if task:
                 (self.conf_ints, self.std_errs, self.boot_ratios,
                  self.boot_debug_dict) = self._bootstrap_test(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
             elif self.pls_alg == "rb":           # :185-209
                 (self.conf_ints, self.std_errs, self.boot_ratios, self.LVcorr,
                  self.boot_debug_dict) = self._boot_rb(U, s, V, nboot, lvcorrs_orig, CI)
+            elif self.pls_alg == "csb":
+                # The reference cannot finish a csb bootstrap: it is handed the q x q
+                # lvintercorrs as lvcorrs_orig (pls_classes.py:1158) and subtracts a
+                # (cells*b x q) array from it (:725).  Same error, before any GPU work.
+                q = self._C.shape[1]
+                rows = self._cond_order.size * np.asarray(Y).shape[1]
+                if np.shape(lvcorrs_orig) != (rows, q) and np.shape(lvcorrs_orig) != (q,) and rows != q:
+                    raise ValueError("operands could not be broadcast together with shapes "
+                                     f"{np.shape(lvcorrs_orig)} ({rows},{q}) ")
+                raise exceptions.NotImplementedError("csb bootstrap (the reference's own raises, see docs)")
             else:                                # :210-237
                 (self.conf_ints, self.conf_ints_T, self.std_errs, self.boot_ratios, self.LVcorr,
                  self.boot_debug_dict) = self._boot_mb(U, s, V, nboot, lvcorrs_orig, Tvsc_orig, CI)
@@ -159,14 +179,17 @@ class _ResampleTestPLS(ResampleTest):
     # permutation tests
     # ------------------------------------------------------------------
     def _perm_mct(self, U, s, niter, threshold=1e-12):
-        """bootstrap_permutation.py:266-464 for mct."""
+        """bootstrap_permutation.py:266-464 for mct and cst (cst: cell means
+        projected on the normalised contrasts, no threshold on s_hat, :429-433)."""
         eng = self._engine
-        k = U.shape[1]
+        Uq = np.asarray(U, dtype=float) if self._C is None else self._C
+        k = Uq.shape[1]
         s[np.abs(s) < threshold] = 0            # in place, like the reference (:295, quirk Q1)
         inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
-        M = self._W.T @ np.asarray(U, dtype=float)      # n x k:  VS = X^T (P^T W^T U)
+        M = self._W.T @ Uq                      # n x k:  VS = X^T (P^T W^T U)
         s_hat = np.sqrt(self._run_perm(eng, k, niter, inds=inds, M=M))
-        s_hat[np.abs(s_hat) < threshold] = 0    # :436
+        if self._C is None:
+            s_hat[np.abs(s_hat) < threshold] = 0    # :436
         ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
         total = np.sum(s_hat ** 2, axis=1)
         debug = {
@@ -206,7 +229,7 @@ class _ResampleTestPLS(ResampleTest):
         eng = self._engine
         co = self._cond_order
         Y = np.asarray(self._Y, dtype=float)
-        U = np.asarray(U, dtype=float)
+        U = np.asarray(U, dtype=float) if self._C is None else self._C     # csb: contrasts (:429-431)
         n, b = Y.shape
         k = U.shape[1]
         bounds = cf.cell_bounds(co)
@@ -220,7 +243,8 @@ class _ResampleTestPLS(ResampleTest):
         for c, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
             cols[:, :, lo:hi] = np.einsum("rib,bj->rji", Yz[:, lo:hi], U[c * b:(c + 1) * b])
         s_hat = np.sqrt(self._run_perm(eng_z, k, niter, cols=cols))
-        s_hat[np.abs(s_hat) < threshold] = 0
+        if self._C is None:
+            s_hat[np.abs(s_hat) < threshold] = 0
         ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
         total = np.sum(s_hat ** 2, axis=1)
         debug = {"s_list": s_hat, "sum_s": total, "sum_perm": total.copy(), "indices": perms}
@@ -236,13 +260,14 @@ class _ResampleTestPLS(ResampleTest):
         co = self._cond_order
         bscan = list(self._bscan)
         Yb = np.asarray(self._Ybscan, dtype=float)
-        U = np.asarray(U, dtype=float)
+        U = np.asarray(U, dtype=float) if self._C is None else self._C     # cmb: contrasts
         ng, nc = co.shape
         n = int(co.sum())
         nb, b = Yb.shape
-        k = U.shape[1]
+        q = U.shape[1]                                       # latent variables (mb: = k)
         nbs = len(bscan)
         per = nc + nbs * b                                   # rows per group in the stacked block
+        k = ng * per                                         # rows of the multiblock
         s[np.abs(s) < threshold] = 0
         mask = cf.bscan_mask(co, bscan)
         bounds_b = cf.cell_bounds(co[:, bscan])
@@ -280,10 +305,14 @@ class _ResampleTestPLS(ResampleTest):
         with np.errstate(divide="ignore", invalid="ignore"):
             scaledU = U[None] / np.sqrt(rownorm2)[:, :, None]                    # D^-1 U per resample
         cols = np.einsum("rki,rkj->rji", A, scaledU)
-        s_hat = np.sqrt(self._run_perm(eng_c, k, niter, cols=cols))              # :404-405
-        per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)          # quirk Q3 (:421-423)
-        s_hat = np.sqrt(per_hat * total_hat[:, None])                             # :424
-        ratio, step = self._ratios(s_hat, org_s, org_s, niter)
+        s_hat = np.sqrt(self._run_perm(eng_c, q, niter, cols=cols))              # :404-405 / :431-432
+        if self._C is None:
+            per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)      # quirk Q3 (:421-423)
+            s_hat = np.sqrt(per_hat * total_hat[:, None])                         # :424
+            ratio, step = self._ratios(s_hat, org_s, org_s, niter)
+        else:
+            # cmb compares with s itself (:433) but steps down against the rescaled org_s (:312-319)
+            ratio, step = self._ratios(s_hat, s, org_s, niter)
         debug = {"s_list": s_hat, "indices": draws, "org_s": org_s}
         return ratio, step, debug
 
@@ -291,11 +320,13 @@ class _ResampleTestPLS(ResampleTest):
     # bootstrap test (mct)
     # ------------------------------------------------------------------
     def _bootstrap_test(self, U, s, V, niter, Tvsc_orig, CI, keep_right_sv):
-        """bootstrap_permutation.py:467-766 for mct, streaming form."""
+        """bootstrap_permutation.py:467-766 for mct and cst, streaming form.  cst:
+        the projection is on the normalised contrasts (VS = permuted.T @ C, :620
+        with U = C) and boot_ratios = V / std_errs (:703)."""
         eng = self._engine
         co = self._cond_order
+        U = np.asarray(U, dtype=float) if self._C is None else self._C
         k = U.shape[1]
-        U = np.asarray(U, dtype=float)
         V = np.asarray(V, dtype=float)
         rank, nranks = dist.world()
         inds = self._draw_on_rank0(lambda: resample.bootstraps(co, niter))
@@ -303,7 +334,9 @@ class _ResampleTestPLS(ResampleTest):
         M = self._W.T @ U
         Wm = operators.cell_mean_operator(co)
         Xm = eng.apply_operator(Wm)                   # k x p cell means of X, on device
-        ref = V * s                                   # observed VS: shift of the moment sums
+        # observed VS (shift of the moment sums and numerator of the ratios):
+        # X_mc.T @ U = V s for mct; R.T @ C = V for cst
+        ref = V * s if self._C is None else V
         res = eng.boot_phase(k, inds=inds[lo:hi], M=M, ref=ref, Xm=Xm, dump=keep_right_sv)
         per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
         per, (S1, S2) = dist.exchange(per, [res["S1"], res["S2"]], niter)
@@ -412,26 +445,28 @@ class _ResampleTestPLS(ResampleTest):
         return conf_int, std_errs, boot_ratios, LVcorr, debug
 
     def _boot_mb(self, U, s, V, niter, lvcorrs_orig, Tvsc_orig, CI):
-        """bootstrap_permutation.py:467-766 for mb."""
+        """bootstrap_permutation.py:467-766 for mb and cmb (cmb: projection on the
+        normalised contrasts, Tdistrib from X itself, ratios V / std_errs; :658-675, :703)."""
         eng = self._engine
         co = self._cond_order
         bscan = list(self._bscan)
         Yb = np.asarray(self._Ybscan, dtype=float)
-        U = np.asarray(U, dtype=float)
+        U = np.asarray(U, dtype=float) if self._C is None else self._C
         V = np.asarray(V, dtype=float)
         ng, nc = co.shape
         n = int(co.sum())
         nb, b = Yb.shape
         nbs = len(bscan)
         per = nc + nbs * b
-        k = U.shape[1]
+        kr = ng * per                                  # rows of the multiblock
+        k = U.shape[1]                                 # latent variables
         bounds_b = cf.cell_bounds(co[:, bscan])
         brows = np.flatnonzero(cf.bscan_mask(co, bscan))                       # bscan index -> row of X
         draws = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Yb, True))
         ti, bi = draws[:, :n], draws[:, n:]
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
-        ref = V * s
+        ref = V * s if self._C is None else V
         # item matrix = [X[ti] (raw) ; X[brows[bi]] z-scored within the bscan cells]
         src = np.concatenate((ti, brows[bi]), axis=1)[lo:hi]
         cell_lo = np.concatenate(([0, n], n + bounds_b[1:]))
@@ -443,7 +478,7 @@ class _ResampleTestPLS(ResampleTest):
             """un-normalised multiblock rows (class_functions.py:479-511) as operators on
             the item matrix: task rows W on the gathered rows, behaviour rows Yz_b."""
             Yz = cf.zscore_cells(Yb[bi[lo:hi][a:z]], bounds_b)
-            A = np.zeros((z - a, k, n + nb))
+            A = np.zeros((z - a, kr, n + nb))
             for g in range(ng):
                 A[:, g * per:g * per + nc, :n] = W[g * nc:(g + 1) * nc]
                 for ci in range(nbs):
@@ -465,9 +500,13 @@ class _ResampleTestPLS(ResampleTest):
         # behaviour latents (:647-650): Xbscan_new @ V_hat = (X @ V_hat)[brows[bi]]
         Lb = np.take_along_axis(Zn, brows[bi][:, :, None].astype(np.int64), axis=1)
         LVcorr = cf.corr_rows(Lb, cf.zscore_cells(Yb[bi], bounds_b), bounds_b)
-        # task distribution (:654-656): cell means of smeanmat(X_new_T) @ V_hat
-        Lt = np.take_along_axis(Zn, ti[:, :, None].astype(np.int64), axis=1)
-        Tdistrib = cf.cell_means_rows(cf.smeanmat_rows(Lt, co, self._mctype), co)
+        if self._C is None:
+            # task distribution (:654-656): cell means of smeanmat(X_new_T) @ V_hat
+            Lt = np.take_along_axis(Zn, ti[:, :, None].astype(np.int64), axis=1)
+            Tdistrib = cf.cell_means_rows(cf.smeanmat_rows(Lt, co, self._mctype), co)
+        else:
+            # cmb (:665-666): cell means of X @ normalize(crossblock.T), X itself
+            Tdistrib = cf.cell_means_rows(Zn, co)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z
         conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :723-725

@@ -8,6 +8,9 @@ methods = {
     "mct": pls_classes._MeanCentreTaskPLS,
     "rb": pls_classes._RegularBehaviourPLS,
     "mb": pls_classes._MultiblockPLS,
+    "cst": pls_classes._ContrastTaskPLS,
+    "csb": pls_classes._ContrastBehaviourPLS,
+    "cmb": pls_classes._ContrastMultiblockPLS,
 }
 
 

@@ -322,3 +322,183 @@ class _MultiblockPLS(PLSBase):
                     mctype=self.mctype, contrasts=None, bscan=self.bscan, Xbscan=self.Xbscan,
                     Ybscan=self.Ybscan, lv=self.lv, CI=self.CI, engine=engine)
         self.U, self.V = self.V, self.U                              # :1557
+
+
+def _contrast_decomposition(engine, rows, C):
+    """class_functions.py:126-162 (_run_pls_contrast) on the device: with M =
+    rows @ Z, CB = C.T @ M = (C.T rows) @ Z; U = C, s = row norms of CB,
+    V = CB.T.  Returns (U, s, V)."""
+    CB = engine.apply_operator(C.T @ rows).cpu().numpy()            # q x p
+    return C, np.sqrt(np.sum(CB ** 2, axis=1)), CB.T
+
+
+def _run_split_half(self, engine, Y, **extra):
+    """The split-half block every class ends with (pls_classes.py:285-316)."""
+    if "num_split" not in self._user_defined_attrs:
+        return
+    self.num_split = int(self.num_split)
+    if self.num_split <= 0:
+        return
+    from . import split_half_resampling
+    self._clip_lv()
+    common = dict(num_split=self.num_split, mctype=getattr(self, "mctype", None),
+                  contrasts=getattr(self, "contrasts", None), engine=engine, **extra)
+    self.pls_repro_tt = split_half_resampling.split_half_test_train(
+        self.pls_alg, self.X, Y, self.cond_order, **common)
+    self.pls_repro_sh = split_half_resampling.split_half(
+        self.pls_alg, self.X, Y, self.cond_order, lv=self.lv, CI=self.CI, **common)
+
+
+@PLSBase._register_subclass("cst")
+class _ContrastTaskPLS(PLSBase):
+    """Contrast task PLS (pls_classes.py:650-928)."""
+
+    def __init__(self, X, groups_sizes, num_conditions, Y=None, cond_order=None, num_perm=1000,
+                 num_boot=1000, mctype=0, contrasts=None, CI=0.95, **kwargs):
+        self._take_kwargs(kwargs)
+        if Y is not None:
+            raise ValueError(f"Do not provide a Y/behavioural matrix for {self._pls_types[self.pls_alg]}.")
+        if len(X.shape) != 2:
+            raise exceptions.ImproperShapeError("Input matrix must be 2-dimensional.")
+        self.X = X
+        self.groups_sizes, self.num_groups = self._get_groups_info(groups_sizes)
+        self.num_conditions = num_conditions
+        self.cond_order = self._resolve_cond_order(cond_order, groups_sizes, num_conditions, X)
+        if contrasts is None:
+            raise exceptions.MissingParameterError("Please provide a contrast matrix.")
+        self.contrasts = cf.normalize(np.asarray(contrasts, dtype=float))
+        self.num_perm, self.num_boot, self.CI = num_perm, num_boot, CI
+        self.mctype = 1 if (num_conditions == 1 and mctype != 1) else mctype
+
+        engine = ProjectionEngine(X)
+        co = np.asarray(self.cond_order)
+        Wm = operators.cell_mean_operator(co)
+        self.R = engine.apply_operator(Wm).cpu().numpy()                         # :853
+        self.U, self.s, self.V = _contrast_decomposition(engine, Wm, self.contrasts)   # :854-856
+        self.lvintercorrs = self.V.T @ self.V
+        self.X_latent = np.dot(self.X, cf.normalize(self.V))
+        Tvsc_orig = Wm @ self.X_latent
+        self.resample_tests = bootstrap_permutation.ResampleTest._create(
+            self.pls_alg, self.X, None, self.U, self.s, self.V, self.cond_order, self.mctype,
+            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, contrast=self.contrasts,
+            Tvsc_orig=Tvsc_orig, CI=self.CI, engine=engine)
+        _run_split_half(self, engine, None)
+        self.U, self.V = self.V, self.U
+
+
+@PLSBase._register_subclass("csb")
+class _ContrastBehaviourPLS(PLSBase):
+    """Contrast behaviour PLS (pls_classes.py:931-1202).  Like the reference,
+    a bootstrap (num_boot > 0) ends in a broadcasting ValueError (the class hands
+    the q x q lvintercorrs to the bootstrap as lvcorrs_orig, :1158)."""
+
+    def __init__(self, X, groups_sizes, num_conditions, Y=None, cond_order=None, num_perm=1000,
+                 num_boot=1000, contrasts=None, CI=0.95, **kwargs):
+        self._take_kwargs(kwargs)
+        if Y is None:
+            raise exceptions.MissingParameterError("Please provide a Y/behavioural matrix.")
+        if len(X.shape) != 2 or len(Y.shape) != 2:
+            raise exceptions.ImproperShapeError("Input matrices must be 2-dimensional.")
+        self.X, self.Y = X, Y
+        self.groups_sizes, self.num_groups = self._get_groups_info(groups_sizes)
+        self.num_conditions = num_conditions
+        self.cond_order = self._resolve_cond_order(cond_order, groups_sizes, num_conditions, X, Y)
+        if contrasts is None:
+            raise exceptions.MissingParameterError("Please provide a contrast matrix.")
+        self.contrasts = cf.normalize(np.asarray(contrasts, dtype=float))
+        _check_behaviour(self.Y, self.cond_order)
+        self.num_perm, self.num_boot, self.CI = num_perm, num_boot, CI
+
+        engine = ProjectionEngine(X)
+        co = np.asarray(self.cond_order)
+        bounds = cf.cell_bounds(co)
+        Xz = engine.gather_zscore(np.arange(X.shape[0]), bounds, np.ones(len(bounds) - 1))[0]
+        eng_z = ProjectionEngine(Xz, device=engine.device, work_limit=engine.work_limit)
+        A = cf.corr_operator(cf.zscore_cells(np.asarray(Y, dtype=float), bounds), bounds)
+        self.R = eng_z.apply_operator(A).cpu().numpy()
+        self.U, self.s, self.V = _contrast_decomposition(eng_z, A, self.contrasts)
+        self.lvintercorrs = self.V.T @ self.V
+        self.X_latent = np.dot(self.X, self.V)
+        self.Y_latent = cf.compute_Y_latents(self.Y, self.U, co)
+        self.resample_tests = bootstrap_permutation.ResampleTest._create(
+            self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, None,
+            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, contrast=self.contrasts,
+            lvcorrs_orig=self.lvintercorrs, CI=self.CI, engine=engine)
+        _run_split_half(self, engine, self.Y)
+        self.U, self.V = self.V, self.U
+
+
+@PLSBase._register_subclass("cmb")
+class _ContrastMultiblockPLS(PLSBase):
+    """Contrast multiblock PLS (pls_classes.py:1561-1925)."""
+
+    def __init__(self, X, groups_sizes, num_conditions, mctype=0, Y=None, cond_order=None,
+                 num_perm=1000, num_boot=1000, contrasts=None, CI=0.95, **kwargs):
+        self._take_kwargs(kwargs)
+        if Y is None:
+            raise exceptions.MissingParameterError("Please provide a Y/behavioural matrix.")
+        if len(X.shape) != 2 or len(Y.shape) != 2:
+            raise exceptions.ImproperShapeError("Input matrices must be 2-dimensional.")
+        self.X, self.Y = X, Y
+        self.groups_sizes, self.num_groups = self._get_groups_info(groups_sizes)
+        self.num_conditions = num_conditions
+        self.mctype = 1 if (num_conditions == 1 and mctype != 1) else mctype
+        self.cond_order = self._resolve_cond_order(cond_order, groups_sizes, num_conditions, X, Y)
+        if "bscan" not in self._user_defined_attrs:
+            self.bscan = [i for i in range(self.num_conditions)]
+        co = np.asarray(self.cond_order)
+        bscan = list(self.bscan)
+        mask = cf.bscan_mask(co, bscan)
+        self.Xbscan, self.Ybscan = self.X[mask], self.Y[mask]
+        _check_behaviour(self.Ybscan, co[:, bscan])
+        self.num_perm, self.num_boot, self.CI = num_perm, num_boot, CI
+        if contrasts is None:
+            raise exceptions.MissingParameterError("Please provide a contrast matrix.")
+        ng, nc = co.shape
+        n = X.shape[0]
+        nb, b = self.Ybscan.shape
+        nbs = len(bscan)
+        per = nc + nbs * b
+        k = ng * per
+        # keep the contrast rows of all task conditions and of the bscan behaviour rows (:1788-1799)
+        Bi = np.zeros((b, nc))
+        Bi[:, bscan] = 1
+        keep = np.tile(np.concatenate([np.ones(nc), Bi.reshape(-1, order="F")]), ng).astype(bool)
+        self.contrasts = cf.normalize(np.asarray(contrasts, dtype=float)[keep, :])
+
+        import torch
+        engine = ProjectionEngine(X)
+        bounds_b = cf.cell_bounds(co[:, bscan])
+        Xzb = engine.gather_zscore(np.flatnonzero(mask), bounds_b, np.ones(len(bounds_b) - 1))[0]
+        eng_c = ProjectionEngine(torch.cat((engine.X, Xzb), dim=0), device=engine.device,
+                                 work_limit=engine.work_limit)
+        Wm = operators.cell_mean_operator(co)                        # cmb: plain cell means (class_functions.py:482)
+        Ab = cf.corr_operator(cf.zscore_cells(np.asarray(self.Ybscan, dtype=float), bounds_b), bounds_b)
+        raw = np.zeros((k, n + nb))
+        for g in range(ng):
+            raw[g * per:g * per + nc, :n] = Wm[g * nc:(g + 1) * nc]
+            raw[g * per + nc:(g + 1) * per, n:] = Ab[g * nbs * b:(g + 1) * nbs * b]
+        G = eng_c.gram_phase(raw[None])[0].cpu().numpy()
+        normed = raw / np.sqrt(np.diag(G)[:k])[:, None]
+        self.multiblock = eng_c.apply_operator(normed).cpu().numpy()
+        self.U, self.s, self.V = _contrast_decomposition(eng_c, normed, self.contrasts)
+
+        T_X_latent = np.dot(self.X, cf.normalize(self.V))
+        B_X_latent = np.dot(self.Xbscan, self.V)
+        self.X_latent = np.vstack((T_X_latent, B_X_latent))
+        Tu, Bu = cf.split_Tu_Bu(self.U, num_conditions, self.Y.shape[1], ng, nbs)
+        Tusc = cf.get_Tusc(Tu, num_conditions, co)
+        Busc = cf.get_Busc(Bu, self.Ybscan, co, bscan)
+        Tvsc_orig = Wm @ T_X_latent
+        self.Bvsc, self.Tvsc, self.Tv, self.Bv = Busc, Tusc, Tu, Bu
+        self.Y_latent = np.vstack([Tusc, Busc])
+        self.vsc, self.usc = self.Y_latent, self.X_latent
+        self.Tusc, self.Busc = T_X_latent, B_X_latent
+        self.lvcorrs = cf.compute_corr_small(B_X_latent, self.Ybscan, co[:, bscan])
+        self.resample_tests = bootstrap_permutation.ResampleTest._create(
+            self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, self.mctype,
+            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, contrast=self.contrasts,
+            bscan=self.bscan, Xbscan=self.Xbscan, Ybscan=self.Ybscan, lvcorrs_orig=self.lvcorrs,
+            Tvsc_orig=Tvsc_orig, CI=self.CI, engine=engine)
+        _run_split_half(self, engine, self.Y, bscan=self.bscan, Xbscan=self.Xbscan, Ybscan=self.Ybscan)
+        self.U, self.V = self.V, self.U

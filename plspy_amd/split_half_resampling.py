@@ -57,7 +57,7 @@ def _draw_splits(pls_alg, cond_order, num_split, n, bscan):
     tables = resample.subject_tables(cond_order)
     alltab = np.concatenate(tables)
     nc = alltab.shape[1]
-    mb = pls_alg == "mb"
+    mb = pls_alg in ("mb", "cmb")
     out = []
     g1 = g2 = None
     for _ in range(num_split):
@@ -86,7 +86,7 @@ def _draw_splits(pls_alg, cond_order, num_split, n, bscan):
         d = dict(x1=i1, x2=i2, y1=i1, y2=i2)
         if mb:
             d.update(b1=t[:half][:, bscan].flatten(), b2=t[half:][:, bscan].flatten())
-        if pls_alg in ("mct", "mb"):
+        if pls_alg in ("mct", "cst", "mb", "cmb"):
             perm = np.random.permutation(n)                          # :282
             d.update(x1=perm[i1], x2=perm[i2])
             if mb:
@@ -98,11 +98,17 @@ def _draw_splits(pls_alg, cond_order, num_split, n, bscan):
     return out, g1, g2
 
 
-def _items_mct(cond_order, mctype, n, splits, g1, g2):
+def _task_operator(co, mctype, centre):
+    """Mean-centring operator (mct / mb) or plain cell means (cst / cmb,
+    split_half_resampling.py:212, class_functions.py:482)."""
+    return operators.mean_centre_operator(co, mctype) if centre else operators.cell_mean_operator(co)
+
+
+def _items_mct(cond_order, mctype, n, splits, g1, g2, centre=True):
     """Stacked operator rows [W1 P1; W2 P2] (2k x n) for every split; Z = X."""
     nc = np.asarray(cond_order).shape[1]
-    W1 = operators.mean_centre_operator(_get_cond_order((sum(g1) * nc,), tuple(g1), nc), mctype)
-    W2 = operators.mean_centre_operator(_get_cond_order((sum(g2) * nc,), tuple(g2), nc), mctype)
+    W1 = _task_operator(_get_cond_order((sum(g1) * nc,), tuple(g1), nc), mctype, centre)
+    W2 = _task_operator(_get_cond_order((sum(g2) * nc,), tuple(g2), nc), mctype, centre)
     k = W1.shape[0]
     S = len(splits)
     rows = np.zeros((S, 2 * k, n))
@@ -141,7 +147,7 @@ def _items_rb(cond_order, Y, splits, g1, g2):
     return rows, gather, k
 
 
-def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2):
+def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2, centre=True):
     """Multiblock PLS: item matrix = [half-1 rows, half-2 rows (raw) ; half-1
     bscan rows, half-2 bscan rows (z-scored within the half's bscan cells)];
     operator rows per half and group = [mean-centring rows ; z-scored behaviour
@@ -157,7 +163,7 @@ def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2):
     halves = []
     for gs in (g1, g2):
         co = _get_cond_order((sum(gs) * nc,), tuple(gs), nc)
-        halves.append(dict(W=operators.mean_centre_operator(co, mctype), n=int(co.sum()),
+        halves.append(dict(W=_task_operator(co, mctype, centre), n=int(co.sum()),
                            bb=cf.cell_bounds(co[:, bscan])))
     n1, n2 = halves[0]["n"], halves[1]["n"]
     nb1, nb2 = int(halves[0]["bb"][-1]), int(halves[1]["bb"][-1])
@@ -183,8 +189,12 @@ def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2):
     return rows, dict(src=src, cell_lo=cell_lo, cell_z=cell_z), k
 
 
-def _decompose(engine, rows, gather, k, row_normalise):
-    """Per item: U1, s1, U2, s2 (NumPy) and G12."""
+def _decompose(engine, rows, gather, k, row_normalise, contrasts=None):
+    """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, G12) from the
+    Jacobi eigen-decompositions of G11 / G22.  With contrasts C (k x q), where
+    _run_pls_contrast (class_functions.py:126-162) gives U = C, s = row norms of
+    C.T M, V = (C.T M).T:  (None, s1, None, None, C.T G12 C) with
+    s1 = sqrt(diag(C.T G11 C))."""
     rank, nranks = dist.world()
     S = rows.shape[0]
     lo, hi = dist.shard_bounds(S, rank, nranks)
@@ -198,10 +208,18 @@ def _decompose(engine, rows, gather, k, row_normalise):
             with np.errstate(divide="ignore", invalid="ignore"):
                 Gh = np.where((d[:, :, None] * d[:, None, :]) > 0, Gh / d[:, :, None] / d[:, None, :], 0.0)
             G = torch.as_tensor(Gh, device=engine.device)
+    else:
+        G = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device)
+    if contrasts is not None:
+        (Gall,), _ = dist.exchange([G[:, :2 * k, :2 * k].contiguous()], [], S)
+        Gall = Gall.cpu().numpy()
+        C = np.asarray(contrasts, dtype=float)
+        s1 = np.sqrt(np.einsum("kq,skl,lq->sq", C, Gall[:, :k, :k], C))
+        return None, s1, None, None, C.T @ Gall[:, :k, k:] @ C
+    if hi > lo:
         e1, v1 = engine.eigh(G, 0, k)
         e2, v2 = engine.eigh(G, k, k)
     else:
-        G = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device)
         e1 = e2 = torch.zeros((0, k), dtype=torch.float64, device=engine.device)
         v1 = v2 = torch.zeros((0, k, k), dtype=torch.float64, device=engine.device)
     G12 = G[:, :k, k:2 * k].contiguous()
@@ -221,8 +239,8 @@ def _inv(s):
 
 
 def _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine):
-    if pls_alg not in ("mct", "rb", "mb"):
-        raise exceptions.NotImplementedError(f"split-half for {pls_alg} is not available yet")
+    if pls_alg not in ("mct", "rb", "mb", "cst", "csb", "cmb"):
+        raise exceptions.NotImplementedError(f"split-half for {pls_alg} is not available")
     cond_order = np.asarray(cond_order)
     n, p = matrix.shape
     engine = engine if engine is not None else ProjectionEngine(matrix)
@@ -234,14 +252,12 @@ def _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine):
         import torch.distributed as td
         td.broadcast_object_list(drawn, src=0)
     splits, g1, g2 = drawn[0]
-    if pls_alg == "mct":
-        rows, gather, k = _items_mct(cond_order, mctype, n, splits, g1, g2)
-    elif pls_alg == "rb":
+    if pls_alg in ("mct", "cst"):
+        rows, gather, k = _items_mct(cond_order, mctype, n, splits, g1, g2, centre=pls_alg == "mct")
+    elif pls_alg in ("rb", "csb"):
         rows, gather, k = _items_rb(cond_order, Y, splits, g1, g2)
     else:
-        rows, gather, k = _items_mb(cond_order, mctype, Y, list(bscan), splits, g1, g2)
-    if p < k:
-        raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
+        rows, gather, k = _items_mb(cond_order, mctype, Y, list(bscan), splits, g1, g2, centre=pls_alg == "mb")
     return engine, rows, gather, k
 
 
@@ -249,9 +265,15 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
                           bscan=None, Xbscan=None, Ybscan=None, engine=None):
     """split_half_resampling.py:23-401."""
     engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
-    U1, s1, _, _, G12 = _decompose(engine, rows, gather, k, pls_alg == "mb")
-    train = np.repeat(s1[:, None, :], k, axis=1)                       # :195 (row broadcast, Q11)
-    test = _inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U1)    # :196
+    d = k if contrasts is None else np.asarray(contrasts).shape[1]             # :79-86
+    if matrix.shape[1] < d:
+        raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
+    U1, s1, _, _, G12 = _decompose(engine, rows, gather, k, pls_alg in ("mb", "cmb"), contrasts)
+    train = np.repeat(s1[:, None, :], d, axis=1)                       # :195 (row broadcast, Q11)
+    if contrasts is None:
+        test = _inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U1)    # :196
+    else:
+        test = G12                                                     # V.T @ M2.T @ U = C.T M1 M2.T C (:220)
     S = num_split
 
     def slab(a):
@@ -262,10 +284,10 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
         return {
             "pls_s_train": tr,
             "pls_s_test": te,
-            "z": [np.mean(te[i, i, :]) / np.std(te[i, i, :], ddof=1) for i in range(k)],       # :390-393
+            "z": [np.mean(te[i, i, :]) / np.std(te[i, i, :], ddof=1) for i in range(d)],       # :390-393
             "pls_s_train_null": tr0,
             "pls_s_test_null": te0,
-            "z_null": [np.mean(te0[i, i, :]) / np.std(te0[i, i, :], ddof=1) for i in range(k)],
+            "z_null": [np.mean(te0[i, i, :]) / np.std(te0[i, i, :], ddof=1) for i in range(d)],
         }
 
 
@@ -273,9 +295,14 @@ def split_half(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts
                Xbscan=None, Ybscan=None, lv=1, CI=0.95, engine=None):
     """split_half_resampling.py:404-861."""
     engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
-    U1, s1, U2, s2, G12 = _decompose(engine, rows, gather, k, pls_alg == "mb")
-    u_rep = (_inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U2)) * _inv(s2)[:, None, :]   # :682
-    v_rep = np.transpose(U1, (0, 2, 1)) @ U2                                                             # :683
+    U1, s1, U2, s2, G12 = _decompose(engine, rows, gather, k, pls_alg in ("mb", "cmb"), contrasts)
+    if contrasts is None:
+        u_rep = (_inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U2)) * _inv(s2)[:, None, :]   # :682
+        v_rep = np.transpose(U1, (0, 2, 1)) @ U2                                                         # :683
+    else:
+        C = np.asarray(contrasts, dtype=float)
+        u_rep = G12                                                    # V1.T @ V2 = C.T M1 M2.T C  (:682)
+        v_rep = np.broadcast_to(C.T @ C, (G12.shape[0],) + (C.shape[1],) * 2)   # U1.T @ U2 = C.T C (:683)
     S = num_split
 
     def slab(a):

@@ -28,6 +28,8 @@ def load_golden(name):
     offs = np.concatenate(([0], np.cumsum(fx["draws_len"])))
     fx["draws"] = [fx["draws_flat"][offs[i]:offs[i + 1]] for i in range(len(fx["draws_len"]))]
     fx.setdefault("Y", None)
+    fx.setdefault("contrasts", None)
+    fx.setdefault("contrasts_in", None)
     return fx
 
 
@@ -44,20 +46,26 @@ def run_oracle_case(fx, sampler=None, use_fixture_svd=True):
     X, Y = fx["X"], fx["Y"]
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
-        obs = orc.observed(alg, X, co, Y=Y, mctype=fx["mctype"], bscan=fx["bscan"])
+        obs = orc.observed(alg, X, co, Y=Y, mctype=fx["mctype"], bscan=fx["bscan"],
+                           contrasts=fx["contrasts_in"])
         if use_fixture_svd:
             U, s, V = fx["U"], fx["s"].copy(), fx["V"]
             if alg == "mct":
                 obs["Tvsc_orig"] = orc.group_condition_means(X @ V, co)
             elif alg == "rb":
                 obs["lvcorrs"] = orc.compute_corr(X @ V, Y, co)
+            elif alg == "cst":
+                obs["Tvsc_orig"] = orc.group_condition_means(X @ orc.normalize(V), co)
+            elif alg == "csb":
+                obs["lvcorrs"] = fx["lvintercorrs"]          # what the class passes (pls_classes.py:1158)
             else:
                 obs["Tvsc_orig"] = orc.group_condition_means(X @ orc.normalize(V), co)
                 obs["lvcorrs"] = orc.compute_corr(obs["Xbscan"] @ V, obs["Ybscan"], co[:, fx["bscan"]])
         else:
             U, s, V = obs["U"], obs["s"], obs["V"]
         sampler = sampler or orc.RecordingSampler()
-        kw = dict(bscan=fx["bscan"], Xbscan=obs.get("Xbscan"), Ybscan=obs.get("Ybscan"), sampler=sampler)
+        kw = dict(bscan=fx["bscan"], Xbscan=obs.get("Xbscan"), Ybscan=obs.get("Ybscan"), sampler=sampler,
+                  contrast=fx["contrasts"])
         out = {"obs": obs}
         if fx["nperm"]:
             out["perm"] = orc.permutation_test(alg, X, Y, U, s, V, co, fx["mctype"], fx["nperm"], **kw)
@@ -68,7 +76,7 @@ def run_oracle_case(fx, sampler=None, use_fixture_svd=True):
                                              Tvsc_orig=obs.get("Tvsc_orig"), **kw)
         if fx["num_split"]:
             skw = dict(mctype=fx["mctype"], bscan=fx["bscan"], Ybscan=obs.get("Ybscan"),
-                       lv=fx["lv"], sampler=sampler)
+                       lv=fx["lv"], sampler=sampler, contrasts=fx["contrasts"])
             out["tt"] = orc.split_half_both(alg, X, Y, co, fx["num_split"], which="tt", **skw)
             out["sh"] = orc.split_half_both(alg, X, Y, co, fx["num_split"], which="sh", **skw)
         out["sampler"] = sampler

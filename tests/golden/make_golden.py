@@ -68,7 +68,7 @@ class DrawRecorder:
 
 
 def run_case(pls, name, method, n_groups, ncond, p, seed, nperm, nboot, mctype=0,
-             nb=0, bscan=None, num_split=0, lv=1, data_seed=0):
+             nb=0, bscan=None, num_split=0, lv=1, data_seed=0, ncontrast=0):
     n = sum(n_groups) * ncond
     rs = np.random.RandomState(data_seed)
     X = rs.randn(n, p) + 0.5 * rs.randn(1, p)       # non-zero voxel means
@@ -83,7 +83,15 @@ def run_case(pls, name, method, n_groups, ncond, p, seed, nperm, nboot, mctype=0
     if nb:
         Y = np.random.RandomState(data_seed + 1).randn(n, nb) + 0.3 * X[:, :nb]
     kwargs = dict(num_perm=nperm, num_boot=nboot, pls_method=method)
-    if method in ("mct", "mb"):
+    contrasts = None
+    if ncontrast:
+        # contrast rows: cst g*c; csb g*c*b; cmb the FULL g*(c + c*b) rows (the
+        # class keeps the rows of the bscan conditions itself)
+        rows = {"cst": len(n_groups) * ncond, "csb": len(n_groups) * ncond * nb,
+                "cmb": len(n_groups) * (ncond + ncond * nb)}[method]
+        contrasts = np.linalg.qr(np.random.RandomState(data_seed + 2).randn(rows, ncontrast))[0]
+        kwargs["contrasts"] = contrasts.copy()
+    if method in ("mct", "mb", "cst", "cmb"):
         kwargs["mctype"] = mctype
     if Y is not None:
         kwargs["Y"] = Y
@@ -114,6 +122,16 @@ def run_case(pls, name, method, n_groups, ncond, p, seed, nperm, nboot, mctype=0
     )
     if Y is not None:
         out["Y"] = Y
+    if contrasts is not None:
+        out["contrasts_in"] = contrasts
+        out["contrasts"] = np.asarray(res.contrasts)
+        if hasattr(res, "lvintercorrs"):
+            out["lvintercorrs"] = np.asarray(res.lvintercorrs)
+    if method in ("cst", "csb"):
+        out["R"] = res.R
+    if method == "cmb":
+        out["multiblock"], out["lvcorrs"] = res.multiblock, res.lvcorrs
+        out["Tusc"], out["Busc"] = res.Tusc, res.Busc
     if method == "mct":
         out["X_means"], out["X_mc"] = res.X_means, res.X_mc
     if method == "rb":
@@ -132,9 +150,9 @@ def run_case(pls, name, method, n_groups, ncond, p, seed, nperm, nboot, mctype=0
         out["conf_lo"], out["conf_hi"] = rt.conf_ints
         out["left_sv_sampled"] = rt.boot_debug_dict["left_sv_sampled"]
         out["right_sv_sampled"] = rt.boot_debug_dict["right_sv_sampled"]
-        if method in ("rb", "mb"):
+        if method in ("rb", "mb", "cmb"):
             out["LVcorr"] = rt.LVcorr
-        if method == "mb":
+        if method in ("mb", "cmb"):
             out["confT_lo"], out["confT_hi"] = rt.conf_ints_T
     if num_split:
         for key, val in res.pls_repro_tt.items():
@@ -162,6 +180,14 @@ def main():
              data_seed=10)
     run_case(pls, "mb_split_g6x5_c3_b2", "mb", (6, 5), 3, 60, 42, 4, 4, mctype=1, nb=2, bscan=(0, 2),
              num_split=5, lv=2, data_seed=11)
+    # contrast variants (the reference's csb bootstrap raises a broadcast
+    # ValueError, so csb fixtures carry no bootstrap)
+    run_case(pls, "cst_g6x5_c3_q2", "cst", (6, 5), 3, 90, 21, 10, 10, ncontrast=2, num_split=5, lv=2,
+             data_seed=12)
+    run_case(pls, "csb_g6x5_c2_b2_q3", "csb", (6, 5), 2, 70, 22, 10, 0, nb=2, ncontrast=3, num_split=4, lv=2,
+             data_seed=13)
+    run_case(pls, "cmb_g6x6_c3_b2_q2", "cmb", (6, 6), 3, 80, 23, 8, 8, nb=2, bscan=(0, 2), ncontrast=2,
+             num_split=4, lv=2, data_seed=14)
 
 
 if __name__ == "__main__":
