@@ -162,10 +162,10 @@ def main():
         f_perm = 2 * k * n * p + 2 * k * k * p
         f_boot = f_perm + 2 * n * k * p
         # flops the MFMA pipe actually executes per resample: U is folded into
-        # the operator (2nkp) and Tdistrib uses the k x p cell means (one padded
-        # 16-wide MFMA tile per 16 batch columns: 32 flop per column-voxel)
+        # the operator (2nkp) and Tdistrib uses the k x p cell means in halves
+        # of four cells (v_mfma_f64_4x4x4_4b: 8 flop per half per column-voxel)
         x_perm = 2 * n * k * p
-        x_boot = x_perm + 32 * k * p
+        x_boot = x_perm + 8 * ((k + 3) // 4) * k * p
         per_launch = NBOOT
         bm = float(np.mean(boot_ms)) if boot_ms else float("nan")
         pm = float(np.mean(perm_ms)) if perm_ms else float("nan")
@@ -191,7 +191,7 @@ def main():
             "end_to_end_resamples_per_s": total / (elapsed + t_index * args.steps / 1.0),
             "host_index_generation_s_per_step": t_index,
             "roofline": {
-                "bound": "mfma", "kernel": "plsr::project_kernel<3, 1> (bootstrap projection)",
+                "bound": "mfma", "kernel": "plsr::project_kernel<3, 1, 2> (bootstrap projection)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": bm, "launches": len(boot_ms),

@@ -62,7 +62,8 @@ extern "C" int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *
   out->Rp = (R + 3) / 4 * 4;
   const int64_t nquads = (int64_t)kp * (out->Rp / 4);
   out->ntiles = (int32_t)((nquads + 3) / 4);
-  out->frag_elems = (int64_t)out->ntiles * out->nk * 64;
+  // + four k-steps of padding: the kernel's fragment prefetch runs 4 steps ahead
+  out->frag_elems = (int64_t)out->ntiles * out->nk * 64 + 4 * 64;
   // the X tile plus the transpose patches must fit the 160 KiB LDS of a CU
   if (project_lds_bytes(out->nk, std::min(period, MAX_PERIOD), true) > 160 * 1024) return PLSR_EUNSUPPORTED;
   return PLSR_OK;
@@ -85,7 +86,7 @@ static int launch_ops(const int32_t *d_inds, const double *d_M, const double *d_
   a.R = lay->R;
   a.nquads = (int32_t)lay_nquads(lay);
   a.ntiles = lay->ntiles;
-  const int64_t total = lay->frag_elems;
+  const int64_t total = (int64_t)lay->ntiles * lay->nk * 64;
   dim3 grid((unsigned)((total + 255) / 256));
   if (d_cols)
     hipLaunchKernelGGL(ops_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -173,46 +174,66 @@ int reduce_slabs(const double *slabs, const Work &w, int width, const plsr_layou
   return check_launch();
 }
 
+using ProjectKernel = void (*)(ProjectArgs);
+
+int launch_kernel(ProjectKernel kern, int mode, const ProjectArgs &a, size_t lds, dim3 grid,
+                  hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      g_last_hip = (int)e;
+      return PLSR_ELAUNCH;
+    }
+  }
+  TimedLaunch tl{};
+  if (g_timing) {
+    (void)hipEventCreate(&tl.a);
+    (void)hipEventCreate(&tl.b);
+    tl.kind = mode;
+    (void)hipEventRecord(tl.a, st);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  if (g_timing) {
+    (void)hipEventRecord(tl.b, st);
+    g_timed.push_back(tl);
+  }
+  return check_launch();
+}
+
+// Bootstrap instances: the period of the quad layout and the number of
+// four-cell halves of the second matrix are compile-time in the hot kernel.
+template <int P>
+ProjectKernel boot_instance(int nh) {
+  switch (nh) {
+    case 0: return project_kernel<P, 1, 0>;
+    case 1: return project_kernel<P, 1, 1>;
+    case 2: return project_kernel<P, 1, 2>;
+    case 3: return project_kernel<P, 1, 3>;
+    default: return project_kernel<P, 1, 4>;
+  }
+}
+
 template <int MODE>
 int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hipStream_t st) {
   const size_t lds = project_lds_bytes(a.nk, period, MODE != 0);
-  dim3 grid((unsigned)nvt, (unsigned)nsplit), block(256);
-#define PLSR_CASE(P)                                                                          \
-  case P: {                                                                                   \
-    auto kern = project_kernel<P, MODE>;                                                      \
-    if (lds > 64 * 1024) {                                                                    \
-      hipError_t e = hipFuncSetAttribute((const void *)kern,                                  \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) {                                                                  \
-        g_last_hip = (int)e;                                                                  \
-        return PLSR_ELAUNCH;                                                                  \
-      }                                                                                       \
-    }                                                                                         \
-    TimedLaunch tl{};                                                                         \
-    if (g_timing) {                                                                           \
-      (void)hipEventCreate(&tl.a);                                                                  \
-      (void)hipEventCreate(&tl.b);                                                                  \
-      tl.kind = MODE;                                                                 \
-      (void)hipEventRecord(tl.a, st);                                                               \
-    }                                                                                         \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                        \
-    if (g_timing) {                                                                           \
-      (void)hipEventRecord(tl.b, st);                                                               \
-      g_timed.push_back(tl);                                                                  \
-    }                                                                                         \
-    break;                                                                                    \
+  dim3 grid((unsigned)nvt, (unsigned)nsplit);
+  ProjectKernel kern = nullptr;
+  if (MODE == 0) {
+    kern = project_kernel<1, 0, 0>;
+  } else {
+    const int nh = (a.k2 + 3) / 4;
+    switch (period) {
+      case 1: kern = MODE == 1 ? boot_instance<1>(nh) : project_kernel<1, 2, -1>; break;
+      case 2: kern = MODE == 1 ? boot_instance<2>(nh) : project_kernel<2, 2, -1>; break;
+      case 3: kern = MODE == 1 ? boot_instance<3>(nh) : project_kernel<3, 2, -1>; break;
+      case 4: kern = MODE == 1 ? boot_instance<4>(nh) : project_kernel<4, 2, -1>; break;
+      case 5: kern = MODE == 1 ? boot_instance<5>(nh) : project_kernel<5, 2, -1>; break;
+      case 6: kern = MODE == 1 ? boot_instance<6>(nh) : project_kernel<6, 2, -1>; break;
+      default: return PLSR_EUNSUPPORTED;
+    }
   }
-  switch (period) {
-    PLSR_CASE(1)
-    PLSR_CASE(2)
-    PLSR_CASE(3)
-    PLSR_CASE(4)
-    PLSR_CASE(5)
-    PLSR_CASE(6)
-    default: return PLSR_EUNSUPPORTED;
-  }
-#undef PLSR_CASE
-  return check_launch();
+  return launch_kernel(kern, MODE, a, lds, grid, st);
 }
 }  // namespace
 

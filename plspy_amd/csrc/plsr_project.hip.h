@@ -67,7 +67,10 @@ __device__ __forceinline__ int xs_index(int row, int v) {
 
 // MODE 0: permutation (norms only); 1: bootstrap (moments, norms, T);
 // 2: bootstrap that also materialises VS (tests, debug dict, observed blocks)
-template <int PERIOD, int MODE>
+// NHT: halves (groups of four cells) of the second matrix, compile-time for the
+// hot bootstrap instance (a run-time count in the unrolled MFMA loop costs ~15 %);
+// -1 = take it from the arguments (dump mode), 0 = no second matrix.
+template <int PERIOD, int MODE, int NHT>
 __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
   constexpr bool BOOT = MODE != 0;
   constexpr bool DUMP = MODE == 2;
@@ -107,13 +110,22 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
 
   // second matrix (cell means of X) as B operand of the voxel contraction:
   // B[k = v = 4*s + g][n = c' = col]
-  double xm[16];
+  // for v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction;
+  // lane = 16 k + 4 b + x: A_b[i = x][k], B_b[k][j = x], D_b[i][j] at lane 16 i + 4 b + j;
+  // probed in microbench/mfma_f64_4x4.hip).  Block b = four batch columns, j = four
+  // cells of "half" h: with k2 <= 12 cells the 16x16x4 shape would waste most of
+  // its N dimension, the 4x4 shape costs 17 instead of 64 cycles per half.
+  // B_b[k][j] = Xm[4 h + j][v0 + 4 step + k] for every b; lane-linear in LDS,
+  // shared by the four waves.
+  const int nh = NHT >= 0 ? NHT : (A.k2 + 3) / 4;                         // halves of 4 cells
+  double *XmS = smem + (size_t)nrows * TV + (size_t)WAVES * 16 * DT_LD;   // [nh][16][64]
   double s1[PERIOD][NT], s2[PERIOD][NT], rf[PERIOD][NT];
   if (BOOT) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int e = wave; e < nh * 16; e += WAVES) {
+      const int h = e >> 4, s = e & 15;
+      const int cell = 4 * h + (lane & 3);
       const int64_t v = v0 + 4 * s + g;
-      xm[s] = (A.Xm != nullptr && col < A.k2 && v < A.p) ? A.Xm[(int64_t)col * A.ldxm + v] : 0.0;
+      XmS[e * 64 + lane] = (A.Xm != nullptr && cell < A.k2 && v < A.p) ? A.Xm[(int64_t)cell * A.ldxm + v] : 0.0;
     }
 #pragma unroll
     for (int sl = 0; sl < PERIOD; ++sl) {
@@ -133,35 +145,40 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
   const int nk = A.nk;
   // blockIdx.y splits the batch tiles (in whole wave x period groups) so that the
   // grid quantises well on 256 CUs; each split owns its own moment partials.
+  // Inside a split every wave takes a CONTIGUOUS run of tiles (a multiple of
+  // PERIOD, so the slot -> latent-variable map holds): its operator fragments
+  // are then one linear stream in memory.
   const int cs = blockIdx.y;
   const int group = WAVES * PERIOD;
   const int gps = ((A.ntiles + group - 1) / group + gridDim.y - 1) / gridDim.y;
   const int t_begin = cs * gps * group;
   const int t_end = min(A.ntiles, t_begin + gps * group);
+  const int run = ((max(t_end - t_begin, 0) + group - 1) / group) * PERIOD;   // tiles per wave
+  const int w_lo = min(t_end, t_begin + wave * run);
+  const int w_hi = min(t_end, w_lo + run);
   const int rem = nk & 3;
 
   // Software pipeline of the main contraction.  `ring` holds this wave's
-  // operator fragments (MFMA A operand) four k-steps ahead of use -- across
-  // tile boundaries too: during a tile's last four k-steps the ring is refilled
-  // from the wave's NEXT tile, so the L2 latency of a fragment load is covered
-  // by 16 MFMAs.  `bn` holds the X fragments (B operand, from LDS) one k-step
-  // ahead.  The loop body has no branches, so MFMAs issue back to back.
+  // operator fragments (MFMA A operand) four k-steps ahead of use.  Because the
+  // wave's tiles are contiguous the prefetch simply runs on into the next tile
+  // (the buffer carries four k-steps of padding at its end), so the L2 latency of
+  // a fragment load is always covered by 16 MFMAs.  `bn` holds the X fragments
+  // (B operand, from LDS) one k-step ahead.  The loop body has no branches.
   double ring[4];
   double bn[NT];
   {
-    const int tf = t_begin + wave * PERIOD;
-    const double *ap0 = A.frag + ((size_t)(tf < t_end ? tf : 0) * nk) * 64 + lane;
+    const double *ap0 = A.frag + ((size_t)w_lo * nk) * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ring[u] = ap0[(u < nk ? u : nk - 1) * 64];
+    for (int u = 0; u < 4; ++u) ring[u] = ap0[(size_t)u * 64];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bn[nt] = Xs[xo[nt]];
   }
 
-  for (int base = t_begin + wave * PERIOD; base < t_end; base += WAVES * PERIOD) {
+  for (int base = w_lo; base < w_hi; base += PERIOD) {
 #pragma unroll
     for (int sl = 0; sl < PERIOD; ++sl) {
       const int t = base + sl;
-      if (t >= t_end) break;
+      if (t >= w_hi) break;
 
       // ---------------- main contraction ----------------
       f64x4 acc[NT];
@@ -169,10 +186,6 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
       for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
       const double *ap = A.frag + ((size_t)t * nk) * 64 + lane;
-      // this wave's next tile (or this one again at the very end: any valid address)
-      int tn = (sl + 1 < PERIOD && t + 1 < t_end) ? t + 1 : base + WAVES * PERIOD;
-      if (tn >= t_end) tn = t;
-      const double *apn = A.frag + ((size_t)tn * nk) * 64 + lane;
 
       auto step = [&](int s, double a) {
         double b[NT];
@@ -187,40 +200,35 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(a, b[nt], acc[nt]);
       };
-      auto fetch = [&](int s) -> double {                    // fragment of absolute k-step s (may run into the next tile)
-        const int sc = s < nk ? s : (s - nk < nk ? s - nk : nk - 1);
+      auto fetch = [&](int s) -> double {      // fragment of k-step s counted from this tile (runs on linearly)
 #if PLSR_ABLATE & 2
-        return 1.0 + sc;
+        return 1.0 + s;
 #else
-        return (s < nk ? ap : apn)[(size_t)sc * 64];
+        return ap[(size_t)s * 64];
 #endif
       };
 
-      if (nk >= 4) {
-        int s = 0;
-        for (; s + 4 <= nk; s += 4) {
+      int s = 0;
+      for (; s + 4 <= nk; s += 4) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double a = ring[u];
-            ring[u] = fetch(s + u + 4);
-            step(s + u, a);
-          }
+        for (int u = 0; u < 4; ++u) {
+          const double a = ring[u];
+          ring[u] = fetch(s + u + 4);
+          step(s + u, a);
         }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          if (u < rem) {
-            const double a = ring[u];
-            ring[u] = fetch(s + u + 4);
-            step(s + u, a);
-          }
-        }
-        // the ring now starts `rem` slots in: rotate it back so slot u = next tile's k-step u
-        if (rem == 1) { const double x = ring[0]; ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3]; ring[3] = x; }
-        if (rem == 2) { double x = ring[0]; ring[0] = ring[2]; ring[2] = x; x = ring[1]; ring[1] = ring[3]; ring[3] = x; }
-        if (rem == 3) { const double x = ring[3]; ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = x; }
-      } else {
-        for (int s = 0; s < nk; ++s) step(s, ap[(size_t)s * 64]);   // tiny n: not pipelined
       }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (u < rem) {
+          const double a = ring[u];
+          ring[u] = fetch(s + u + 4);
+          step(s + u, a);
+        }
+      }
+      // the ring now starts `rem` slots in: rotate it back so slot u = next tile's k-step u
+      if (rem == 1) { const double x = ring[0]; ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3]; ring[3] = x; }
+      if (rem == 2) { double x = ring[0]; ring[0] = ring[2]; ring[2] = x; x = ring[1]; ring[1] = ring[3]; ring[3] = x; }
+      if (rem == 3) { const double x = ring[3]; ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = x; }
 
       // quad / resample bookkeeping of this lane group
       const int q = 4 * t + g;
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
       // one 16-voxel block at a time through a 16 x 18 (padded) per-wave patch:
       // written in accumulator layout, read back as A[m = col][k = g]
       double nsq = 0.0;
-      f64x4 accT = (f64x4){0.0, 0.0, 0.0, 0.0};
+      double accT[4] = {0.0, 0.0, 0.0, 0.0};                 // one 4x4x4_4b accumulator per half
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -287,17 +295,25 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           nsq = fma(av[s], av[s], nsq);
-          if (BOOT) accT = mfma_f64(av[s], xm[4 * nt + s], accT);
+          if (BOOT) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+              if (h < nh)
+                accT[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s], XmS[((h * 16) + 4 * nt + s) * 64 + lane],
+                                                             accT[h], 0, 0, 0);
+          }
         }
       }
       nsq += __shfl_xor(nsq, 16);
       nsq += __shfl_xor(nsq, 32);
       if (g == 0) A.norm_part[vt * C + (int64_t)t * 16 + col] = nsq;
       if (BOOT && A.k2 > 0) {
-        if (col < A.k2) {
+        // D_b[i][j] sits at lane 16 i + 4 b + j: batch column c = 4 b + i, cell = 4 h + j
+        const int c = 4 * ((lane & 15) >> 2) + (lane >> 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            A.T_part[(vt * C + (int64_t)t * 16 + g + 4 * r) * A.k2 + col] = accT[r];
+        for (int h = 0; h < 4; ++h) {
+          const int cell = 4 * h + (lane & 3);
+          if (h < nh && cell < A.k2) A.T_part[(vt * C + (int64_t)t * 16 + c) * A.k2 + cell] = accT[h];
         }
       }
     }
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
 }
 
 inline size_t project_lds_bytes(int nk, int period, bool boot) {
-  size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD) * sizeof(double);
+  size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD + (boot ? 4 * 16 * 64 : 0)) * sizeof(double);
   size_t b = boot ? (size_t)WAVES * period * 4 * TV * sizeof(double) : 0;
   return a > b ? a : b;
 }

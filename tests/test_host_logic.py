@@ -40,7 +40,7 @@ def test_layout(lib, k, kp, period):
     assert (lay.kp, lay.period, lay.nk, lay.Rp) == (kp, period, 15, 12)
     assert (4 * lay.period) % lay.kp == 0          # the slot -> latent-variable map repeats
     assert lay.ntiles == -(-(lay.kp * lay.Rp // 4) // 4)
-    assert lay.frag_elems == lay.ntiles * lay.nk * 64
+    assert lay.frag_elems == lay.ntiles * lay.nk * 64 + 4 * 64      # + prefetch padding
 
 
 def test_layout_rejects(lib):
