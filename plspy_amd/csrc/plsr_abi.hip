@@ -65,7 +65,7 @@ extern "C" int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *
   // + four k-steps of padding: the kernel's fragment prefetch runs 4 steps ahead
   out->frag_elems = (int64_t)out->ntiles * out->nk * 64 + 4 * 64;
   // the X tile plus the transpose patches must fit the 160 KiB LDS of a CU
-  if (project_lds_bytes(out->nk, std::min(period, MAX_PERIOD), true) > 160 * 1024) return PLSR_EUNSUPPORTED;
+  if (project_lds_bytes(out->nk, std::min(period, MAX_PERIOD), true, 4, (int)out->kp) > 160 * 1024) return PLSR_EUNSUPPORTED;
   return PLSR_OK;
 }
 
@@ -216,7 +216,10 @@ ProjectKernel boot_instance(int nh) {
 
 template <int MODE>
 int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hipStream_t st) {
-  const size_t lds = project_lds_bytes(a.nk, period, MODE != 0);
+  size_t lds = project_lds_bytes(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp);
+#if PLSR_ABLATE & 256
+  if (MODE == 0) lds += 40 * 1024;   // dev: force the permutation kernel down to two workgroups per CU
+#endif
   dim3 grid((unsigned)nvt, (unsigned)nsplit);
   ProjectKernel kern = nullptr;
   if (MODE == 0) {

@@ -33,6 +33,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int TV = 64;         // voxels per workgroup
 constexpr int NT = TV / 16;    // MFMA N-tiles per workgroup
 constexpr int DT_LD = 18;      // padded row of the per-wave 16 x 16 transpose patch
+constexpr int XM_LD = 72;      // padded row of the cell-mean tile
 constexpr int WAVES = 4;
 constexpr int MAX_PERIOD = 6;
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ int xs_index(int row, int v) {
 // hot bootstrap instance (a run-time count in the unrolled MFMA loop costs ~15 %);
 // -1 = take it from the arguments (dump mode), 0 = no second matrix.
 template <int PERIOD, int MODE, int NHT>
-__global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
+__global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
   constexpr bool BOOT = MODE != 0;
   constexpr bool DUMP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -115,27 +116,31 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
   // probed in microbench/mfma_f64_4x4.hip).  Block b = four batch columns, j = four
   // cells of "half" h: with k2 <= 12 cells the 16x16x4 shape would waste most of
   // its N dimension, the 4x4 shape costs 17 instead of 64 cycles per half.
-  // B_b[k][j] = Xm[4 h + j][v0 + 4 step + k] for every b; lane-linear in LDS,
-  // shared by the four waves.
+  // B_b[k][j] = Xm[4 h + j][v0 + 4 step + k] for every b: the four b-lanes read the
+  // same LDS word (broadcast) and the padded row (XM_LD = 72) puts the four cells of a
+  // half 16 banks apart, so the read is conflict free.  Shared by the four waves.
   const int nh = NHT >= 0 ? NHT : (A.k2 + 3) / 4;                         // halves of 4 cells
-  double *XmS = smem + (size_t)nrows * TV + (size_t)WAVES * 16 * DT_LD;   // [nh][16][64]
-  double s1[PERIOD][NT], s2[PERIOD][NT], rf[PERIOD][NT];
+  double *XmS = smem + (size_t)nrows * TV + (size_t)WAVES * 16 * DT_LD;   // [4 nh cells][XM_LD]
+  // shift of the streaming moments (observed V*s), [kp][64 voxels], zero for padding
+  double *RfS = XmS + (size_t)nh * 4 * XM_LD;
+  double s1[PERIOD][NT], s2[PERIOD][NT];
   if (BOOT) {
-    for (int e = wave; e < nh * 16; e += WAVES) {
-      const int h = e >> 4, s = e & 15;
-      const int cell = 4 * h + (lane & 3);
-      const int64_t v = v0 + 4 * s + g;
-      XmS[e * 64 + lane] = (A.Xm != nullptr && cell < A.k2 && v < A.p) ? A.Xm[(int64_t)cell * A.ldxm + v] : 0.0;
+    for (int e = tid; e < A.kp * TV; e += 256) {
+      const int j = e >> 6;
+      const int64_t v = v0 + (e & 63);
+      RfS[e] = (A.ref != nullptr && j < A.k && v < A.p) ? A.ref[v * A.k + j] : 0.0;
+    }
+    for (int cell = wave; cell < nh * 4; cell += WAVES) {
+      const int64_t v = v0 + lane;
+      XmS[cell * XM_LD + lane] =
+          (A.Xm != nullptr && cell < A.k2 && v < A.p) ? A.Xm[(int64_t)cell * A.ldxm + v] : 0.0;
     }
 #pragma unroll
     for (int sl = 0; sl < PERIOD; ++sl) {
-      const int j = (4 * sl + g) % A.kp;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int64_t v = v0 + nt * 16 + col;
         s1[sl][nt] = 0.0;
         s2[sl][nt] = 0.0;
-        rf[sl][nt] = (A.ref != nullptr && j < A.k && v < A.p) ? A.ref[v * A.k + j] : 0.0;
       }
     }
   }
@@ -239,12 +244,22 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
       if (BOOT) {
         // ---------------- streaming moments over resamples ----------------
         const int nvalid = live ? min(4, A.R - 4 * bg) : 0;   // resamples of this quad that exist
+        double rf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rf[nt] = RfS[j * TV + nt * 16 + col];
+#if PLSR_ABLATE & 8
+        if (nvalid == 77) {
+          s1[sl][0] += acc[0][0];
+          s2[sl][0] += acc[1][0];
+        } else if (nvalid == 78) {
+#else
         if (__builtin_expect(__all(nvalid == 4), 1)) {
+#endif
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const double d = acc[nt][r] - rf[sl][nt];
+              const double d = acc[nt][r] - rf[nt];
               s1[sl][nt] += d;
               s2[sl][nt] = fma(d, d, s2[sl][nt]);
             }
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
           for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const double d = (r < nvalid) ? acc[nt][r] - rf[sl][nt] : 0.0;
+              const double d = (r < nvalid) ? acc[nt][r] - rf[nt] : 0.0;
               s1[sl][nt] += d;
               s2[sl][nt] = fma(d, d, s2[sl][nt]);
             }
@@ -285,6 +300,11 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
       double accT[4] = {0.0, 0.0, 0.0, 0.0};                 // one 4x4x4_4b accumulator per half
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+#if PLSR_ABLATE & 64
+        double av[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = acc[nt][r];
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) Dt[(g + 4 * r) * DT_LD + col] = acc[nt][r];
         __builtin_amdgcn_wave_barrier();
@@ -292,22 +312,28 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) av[s] = Dt[col * DT_LD + 4 * s + g];
         __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           nsq = fma(av[s], av[s], nsq);
-          if (BOOT) {
+          if (BOOT && !(PLSR_ABLATE & 16)) {
 #pragma unroll
             for (int h = 0; h < 4; ++h)
               if (h < nh)
-                accT[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s], XmS[((h * 16) + 4 * nt + s) * 64 + lane],
-                                                             accT[h], 0, 0, 0);
+                accT[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                    av[s], XmS[(4 * h + (lane & 3)) * XM_LD + 16 * nt + 4 * s + g], accT[h], 0, 0, 0);
           }
         }
       }
       nsq += __shfl_xor(nsq, 16);
       nsq += __shfl_xor(nsq, 32);
-      if (g == 0) A.norm_part[vt * C + (int64_t)t * 16 + col] = nsq;
-      if (BOOT && A.k2 > 0) {
+#if PLSR_ABLATE & 32
+      if (nsq == 77.0)
+#else
+      if (g == 0)
+#endif
+        A.norm_part[vt * C + (int64_t)t * 16 + col] = nsq;
+      if (BOOT && A.k2 > (PLSR_ABLATE & 32 ? 1000 : 0)) {
         // D_b[i][j] sits at lane 16 i + 4 b + j: batch column c = 4 b + i, cell = 4 h + j
         const int c = 4 * ((lane & 15) >> 2) + (lane >> 4);
 #pragma unroll
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
     }
   }
 
-  if (BOOT) {
+  if (BOOT && !(PLSR_ABLATE & 128)) {
     // ---- fold the per-wave, per-quad-slot moment registers into S1/S2 ----
     // scratch[wave][slot][g][v]   (aliases the X tile; all waves are done with it)
     double *red = smem;
@@ -349,8 +375,9 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjectArgs A) {
   }
 }
 
-inline size_t project_lds_bytes(int nk, int period, bool boot) {
-  size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD + (boot ? 4 * 16 * 64 : 0)) * sizeof(double);
+inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp) {
+  size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD + (boot ? nh * 4 * XM_LD + kp * TV : 0)) *
+             sizeof(double);
   size_t b = boot ? (size_t)WAVES * period * 4 * TV * sizeof(double) : 0;
   return a > b ? a : b;
 }
