@@ -117,9 +117,13 @@ def main():
     Md = eng.dev(M)
 
     def step():
+        # the two phases are independent: the HBM-bound slab reductions that end the
+        # bootstrap phase run on the engine's tail stream and overlap the MFMA-bound
+        # permutation kernel (the projection kernels themselves stay serialised)
+        res = eng.boot_phase(k, inds=d_boot, M=Md, ref=ref, Xm=Xm, overlap_tail=True)
         ssq = eng.perm_phase(k, inds=d_perm, M=Md)
+        eng.join()
         (ssq_all,), _ = dist.exchange([ssq], [], RP)
-        res = eng.boot_phase(k, inds=d_boot, M=Md, ref=ref, Xm=Xm)
         (bs, T), (S1, S2) = dist.exchange([res["ssq"], res["T"]], [res["S1"], res["S2"]], RB)
         sd, ratio = eng.boot_finalize(S1, S2, RB, num=ref)
         return ssq_all, bs, T, sd, ratio

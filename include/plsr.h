@@ -219,6 +219,20 @@ int plsr_rng_bootstraps(uint32_t *key, int32_t *pos, const int32_t *table,
                         int32_t *out);
 
 /*
+ * Optional overlap of the reduction tail.  plsr_boot_batch ends with HBM-bound
+ * kernels (moment merges, slab sums of the norm and T partials) that do not
+ * need the matrix cores.  With a tail stream set (per calling thread; NULL
+ * restores the default), plsr_boot_batch enqueues the projection kernel on
+ * `stream` and the reductions on the tail stream, ordered after the projection
+ * by an event, so that whatever the caller enqueues next on `stream` overlaps
+ * them.  The outputs (d_S1, d_S2, d_ssq, d_T) and d_work are then owned by the
+ * tail stream: the caller must make its stream wait for the tail stream before
+ * touching them.  plsr_boot_batch itself makes `stream` wait for the tail stream
+ * on entry (consecutive batches share a workspace).
+ */
+int plsr_set_tail_stream(void *stream);
+
+/*
  * Kernel timing for the roofline report (bench.py).  When enabled, every
  * projection-kernel launch made by plsr_perm_batch / plsr_boot_batch is
  * bracketed by hipEvents recorded on the launch stream.  plsr_timing_collect

@@ -118,16 +118,28 @@ class _ResampleTestPLS(ResampleTest):
             # the contrast variants use the plain cell means as task block (:389, class_functions.py:482)
             self._W = operators.cell_mean_operator(self._cond_order)
 
+        # Task variants: the two tests are independent once their indices are drawn
+        # (permutation draws first, as in the reference), so the bootstrap kernel is
+        # enqueued first and its HBM-bound reduction tail overlaps the permutation
+        # kernel; host post-processing follows in the reference's order.
+        finish_perm = finish_boot = None
+        if task:
+            if nperm > 0:
+                finish_perm = self._perm_mct_start(U, s, nperm)
+            if nboot > 0:
+                finish_boot = self._bootstrap_test_start(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
         if nperm > 0:
-            perm = self._perm_mct if task else (self._perm_rb if behav else self._perm_mb)
-            self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = perm(U, s, nperm)
+            if task:
+                self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = finish_perm()
+            else:
+                perm = self._perm_rb if behav else self._perm_mb
+                self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = perm(U, s, nperm)
         else:                                   # bootstrap_permutation.py:181-182
             self.permute_ratio = "NA"
             self.stepdown_ratio = "NA"
         if nboot > 0:
             if task:
-                (self.conf_ints, self.std_errs, self.boot_ratios,
-                 self.boot_debug_dict) = self._bootstrap_test(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
+                self.conf_ints, self.std_errs, self.boot_ratios, self.boot_debug_dict = finish_boot()
             elif self.pls_alg == "rb":           # :185-209
                 (self.conf_ints, self.std_errs, self.boot_ratios, self.LVcorr,
                  self.boot_debug_dict) = self._boot_rb(U, s, V, nboot, lvcorrs_orig, CI)
@@ -178,29 +190,37 @@ class _ResampleTestPLS(ResampleTest):
     # ------------------------------------------------------------------
     # permutation tests
     # ------------------------------------------------------------------
-    def _perm_mct(self, U, s, niter, threshold=1e-12):
+    def _perm_mct_start(self, U, s, niter, threshold=1e-12):
         """bootstrap_permutation.py:266-464 for mct and cst (cst: cell means
-        projected on the normalised contrasts, no threshold on s_hat, :429-433)."""
+        projected on the normalised contrasts, no threshold on s_hat, :429-433).
+        Draws the indices now; the returned callable runs the kernel and the
+        host summary."""
         eng = self._engine
         Uq = np.asarray(U, dtype=float) if self._C is None else self._C
         k = Uq.shape[1]
         s[np.abs(s) < threshold] = 0            # in place, like the reference (:295, quirk Q1)
         inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
         M = self._W.T @ Uq                      # n x k:  VS = X^T (P^T W^T U)
-        s_hat = np.sqrt(self._run_perm(eng, k, niter, inds=inds, M=M))
-        if self._C is None:
-            s_hat[np.abs(s_hat) < threshold] = 0    # :436
-        ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
-        total = np.sum(s_hat ** 2, axis=1)
-        debug = {
-            "s_list": s_hat,
-            # U is square orthogonal, so sum(permuted**2) == sum(s_hat**2); the
-            # reference stores the two under swapped keys (quirk Q5)
-            "sum_s": total,
-            "sum_perm": total.copy(),
-            "indices": inds,
-        }
-        return ratio, step, debug
+
+        def finish():
+            s_hat = np.sqrt(self._run_perm(eng, k, niter, inds=inds, M=M))
+            if self._C is None:
+                s_hat[np.abs(s_hat) < threshold] = 0    # :436
+            ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
+            total = np.sum(s_hat ** 2, axis=1)
+            debug = {
+                "s_list": s_hat,
+                # U is square orthogonal, so sum(permuted**2) == sum(s_hat**2); the
+                # reference stores the two under swapped keys (quirk Q5)
+                "sum_s": total,
+                "sum_perm": total.copy(),
+                "indices": inds,
+            }
+            return ratio, step, debug
+        return finish
+
+    def _perm_mct(self, U, s, niter, threshold=1e-12):
+        return self._perm_mct_start(U, s, niter, threshold)()
 
     def _draw_behaviour_perms(self, Ysrc, niter, with_task):
         """Row permutations of the behaviour block (and, for multiblock, the task
@@ -320,9 +340,14 @@ class _ResampleTestPLS(ResampleTest):
     # bootstrap test (mct)
     # ------------------------------------------------------------------
     def _bootstrap_test(self, U, s, V, niter, Tvsc_orig, CI, keep_right_sv):
+        return self._bootstrap_test_start(U, s, V, niter, Tvsc_orig, CI, keep_right_sv)()
+
+    def _bootstrap_test_start(self, U, s, V, niter, Tvsc_orig, CI, keep_right_sv):
         """bootstrap_permutation.py:467-766 for mct and cst, streaming form.  cst:
         the projection is on the normalised contrasts (VS = permuted.T @ C, :620
-        with U = C) and boot_ratios = V / std_errs (:703)."""
+        with U = C) and boot_ratios = V / std_errs (:703).  Draws the indices and
+        enqueues the kernels now (reductions on the engine's tail stream); the
+        returned callable joins and does the host summary."""
         eng = self._engine
         co = self._cond_order
         U = np.asarray(U, dtype=float) if self._C is None else self._C
@@ -337,7 +362,13 @@ class _ResampleTestPLS(ResampleTest):
         # observed VS (shift of the moment sums and numerator of the ratios):
         # X_mc.T @ U = V s for mct; R.T @ C = V for cst
         ref = V * s if self._C is None else V
-        res = eng.boot_phase(k, inds=inds[lo:hi], M=M, ref=ref, Xm=Xm, dump=keep_right_sv)
+        res = eng.boot_phase(k, inds=inds[lo:hi], M=M, ref=ref, Xm=Xm, dump=keep_right_sv,
+                             overlap_tail=True)
+        return lambda: self._bootstrap_test_finish(res, inds, niter, ref, V, Tvsc_orig, CI, keep_right_sv)
+
+    def _bootstrap_test_finish(self, res, inds, niter, ref, V, Tvsc_orig, CI, keep_right_sv):
+        eng = self._engine
+        eng.join()
         per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
         per, (S1, S2) = dist.exchange(per, [res["S1"], res["S2"]], niter)
         sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)          # :695, :701

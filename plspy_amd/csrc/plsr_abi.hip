@@ -22,6 +22,23 @@ bool g_timing = false;
 std::vector<TimedLaunch> g_timed;
 }  // namespace
 
+// optional side stream for the reduction tail of plsr_boot_batch
+static thread_local hipStream_t g_tail = nullptr;
+static thread_local hipEvent_t g_chain_ev = nullptr;
+
+// `after` waits for everything enqueued so far on `before`
+static int chain(hipStream_t before, hipStream_t after) {
+  if (!g_chain_ev && hipEventCreateWithFlags(&g_chain_ev, hipEventDisableTiming) != hipSuccess)
+    return PLSR_ELAUNCH;
+  hipError_t e = hipEventRecord(g_chain_ev, before);
+  if (e == hipSuccess) e = hipStreamWaitEvent(after, g_chain_ev, 0);
+  if (e != hipSuccess) {
+    g_last_hip = (int)e;
+    return PLSR_ELAUNCH;
+  }
+  return PLSR_OK;
+}
+
 static inline int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -305,9 +322,20 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   a.S2 = w.mom_part + (size_t)w.nsplit * p * lay->k;
   a.vs_dump = d_vs_dump;
   hipStream_t st = (hipStream_t)stream;
+  if (g_tail) {
+    // the previous batch's reductions (tail stream) read the same workspace
+    rc = chain(g_tail, st);
+    if (rc) return rc;
+  }
   rc = d_vs_dump ? launch_project<2>(a, lay->period, w.nvt, w.nsplit, st)
                  : launch_project<1>(a, lay->period, w.nvt, w.nsplit, st);
   if (rc) return rc;
+  if (g_tail) {
+    // merges and slab reductions follow the projection on the tail stream
+    rc = chain(st, g_tail);
+    if (rc) return rc;
+    st = g_tail;
+  }
   {
     const int64_t cnt = p * lay->k;
     dim3 g((unsigned)((cnt + 255) / 256));
@@ -331,6 +359,11 @@ extern "C" int plsr_boot_finalize(const double *d_S1, const double *d_S2, const 
   hipLaunchKernelGGL(boot_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_S1, d_S2,
                      d_num, count, 1.0 / (double)R, d_std, d_ratio);
   return check_launch();
+}
+
+extern "C" int plsr_set_tail_stream(void *stream) {
+  g_tail = (hipStream_t)stream;
+  return PLSR_OK;
 }
 
 extern "C" int plsr_timing_enable(int on) {

@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bn[nt] = xr[xo[nt]];
 #endif
+        // keep the next step's LDS reads (and the fragment prefetch issued by the
+        // caller) ahead of this step's MFMAs; the scheduler otherwise sinks them
+        // below and exposes the LDS latency at every k-step
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(a, b[nt], acc[nt]);
       };
@@ -217,17 +221,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
       for (; s + 4 <= nk; s += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const double a = ring[u];
+          // refill the slot after the MFMAs that read it have been issued: the load
+          // can then target the same register (no end-of-chunk copies / vmcnt(0))
+          step(s + u, ring[u]);
           ring[u] = fetch(s + u + 4);
-          step(s + u, a);
         }
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (u < rem) {
-          const double a = ring[u];
+          step(s + u, ring[u]);
           ring[u] = fetch(s + u + 4);
-          step(s + u, a);
         }
       }
       // the ring now starts `rem` slots in: rotate it back so slot u = next tile's k-step u

@@ -5,6 +5,7 @@ batches of resamples through the C-ABI library (include/plsr.h) on torch's
 current HIP stream.  torch is used for memory, streams and (in dist.py)
 torch.distributed only; every arithmetic step on the resampling path is a
 hand-written gfx950 kernel behind the ABI."""
+import contextlib
 import ctypes
 
 import numpy as np
@@ -19,6 +20,15 @@ def _ptr(t):
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Lane:
+    """Scratch of one phase kind (the permutation and bootstrap phases keep
+    separate scratch so that one's reductions may overlap the other's kernel)."""
+
+    def __init__(self):
+        self.work = None
+        self.frag = None
 
 
 class ProjectionEngine:
@@ -38,8 +48,8 @@ class ProjectionEngine:
         self.X = X.to(device=self.device, dtype=torch.float64).contiguous()
         self.n, self.p = self.X.shape
         self.work_limit = int(work_limit)
-        self._work = None
-        self._frag = None
+        self._lanes = {}
+        self._tail = None
 
     # -- helpers -----------------------------------------------------------
     def dev(self, a, dtype=torch.float64):
@@ -62,15 +72,25 @@ class ProjectionEngine:
         nb = max(1, self.work_limit // max(per4, 1))
         return int(min((R + 3) // 4 * 4, nb * 4))
 
-    def _scratch(self, lay, k2):
+    def _scratch(self, lay, k2, lane=None):
+        L = self._lanes.get(lane)
+        if L is None:
+            L = self._lanes[lane] = _Lane()
         need = self.lib.plsr_batch_workspace_bytes(ctypes.byref(lay), self.p, k2)
-        if self._work is None or self._work.numel() < need:
-            self._work = None
-            self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if self._frag is None or self._frag.numel() < lay.frag_elems:
-            self._frag = None
-            self._frag = torch.empty(lay.frag_elems, dtype=torch.float64, device=self.device)
-        return self._work, self._frag, need
+        if L.work is None or L.work.numel() < need:
+            L.work = None
+            L.work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if L.frag is None or L.frag.numel() < lay.frag_elems:
+            L.frag = None
+            L.frag = torch.empty(lay.frag_elems, dtype=torch.float64, device=self.device)
+        return L.work, L.frag, need
+
+    # -- overlapped reduction tail ------------------------------------------
+    def join(self):
+        """Current stream waits for the reduction tails of bootstrap phases
+        started with ``overlap_tail=True``; call before reading their results."""
+        if self._tail is not None:
+            torch.cuda.current_stream().wait_stream(self._tail)
 
     def _build_ops(self, lay, frag, inds=None, M=None, cols=None):
         if cols is not None:
@@ -94,7 +114,7 @@ class ProjectionEngine:
         for lo in range(0, R, step):
             hi = min(R, lo + step)
             lay = self.layout(k, hi - lo)
-            work, frag, need = self._scratch(lay, 0)
+            work, frag, need = self._scratch(lay, 0, "perm")
             if cols is not None:
                 self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
             else:
@@ -105,9 +125,13 @@ class ProjectionEngine:
         return out
 
     # -- bootstrap -----------------------------------------------------------
-    def boot_phase(self, k, inds=None, M=None, cols=None, ref=None, Xm=None, dump=False):
+    def boot_phase(self, k, inds=None, M=None, cols=None, ref=None, Xm=None, dump=False,
+                   overlap_tail=False):
         """Streams a bootstrap phase.  Returns dict(S1, S2 (p x k shifted
-        moments), ssq (R x k), T (R x k x k2) or None, vs (R x p x k) or None)."""
+        moments), ssq (R x k), T (R x k x k2) or None, vs (R x p x k) or None).
+        With ``overlap_tail`` the slab reductions that end each batch run on a
+        side stream (so the next phase's kernel overlaps them); ``join()`` before
+        reading the results."""
         R = int(inds.shape[0] if inds is not None else cols.shape[0])
         refd = self.dev(ref)
         Xmd = self.dev(Xm)
@@ -120,20 +144,29 @@ class ProjectionEngine:
         if R:
             step = self.batch_size(k, k2, R)
             Md = self.dev(M)
-            for lo in range(0, R, step):
-                hi = min(R, lo + step)
-                lay = self.layout(k, hi - lo)
-                work, frag, need = self._scratch(lay, k2)
-                if cols is not None:
-                    self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
-                else:
-                    self._build_ops(lay, frag, inds=self.dev(inds[lo:hi], torch.int32), M=Md)
-                _lib.check(self.lib.plsr_boot_batch(
-                    _ptr(self.X), self.X.stride(0), self.p, _ptr(frag), ctypes.byref(lay),
-                    _ptr(refd), _ptr(Xmd), Xmd.stride(0) if k2 else 0, k2,
-                    _ptr(S1), _ptr(S2), _ptr(ssq[lo:hi]), _ptr(T[lo:hi]) if k2 else _ptr(None),
-                    _ptr(vs[lo:hi]) if dump else _ptr(None), _ptr(work), need, _stream()),
-                    "plsr_boot_batch")
+            if overlap_tail and self._tail is None:
+                self._tail = torch.cuda.Stream(device=self.device)
+            if not overlap_tail:
+                self.join()          # an earlier overlapped tail may still read the bootstrap scratch
+            tail = ctypes.c_void_p(self._tail.cuda_stream) if overlap_tail else ctypes.c_void_p(0)
+            _lib.check(self.lib.plsr_set_tail_stream(tail), "plsr_set_tail_stream")
+            try:
+                for lo in range(0, R, step):
+                    hi = min(R, lo + step)
+                    lay = self.layout(k, hi - lo)
+                    work, frag, need = self._scratch(lay, k2, "boot")
+                    if cols is not None:
+                        self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
+                    else:
+                        self._build_ops(lay, frag, inds=self.dev(inds[lo:hi], torch.int32), M=Md)
+                    _lib.check(self.lib.plsr_boot_batch(
+                        _ptr(self.X), self.X.stride(0), self.p, _ptr(frag), ctypes.byref(lay),
+                        _ptr(refd), _ptr(Xmd), Xmd.stride(0) if k2 else 0, k2,
+                        _ptr(S1), _ptr(S2), _ptr(ssq[lo:hi]), _ptr(T[lo:hi]) if k2 else _ptr(None),
+                        _ptr(vs[lo:hi]) if dump else _ptr(None), _ptr(work), need, _stream()),
+                        "plsr_boot_batch")
+            finally:
+                self.lib.plsr_set_tail_stream(ctypes.c_void_p(0))
         return {"S1": S1, "S2": S2, "ssq": ssq, "T": T, "vs": vs, "R": R}
 
     def boot_finalize(self, S1, S2, R, num=None):

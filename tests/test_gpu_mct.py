@@ -149,3 +149,34 @@ def test_full_size_properties():
     np.testing.assert_allclose(sd.cpu().numpy()[sub][:, live], np.std(direct, axis=0)[:, live],
                                rtol=1e-9, atol=1e-13)
     torch.cuda.synchronize()
+
+
+def test_overlapped_tail_is_bit_identical():
+    """plsr_set_tail_stream: running the bootstrap reductions on the tail stream
+    (with a permutation phase enqueued behind the projection kernel, and the
+    phase cut into several batches sharing one workspace) changes nothing."""
+    import torch
+    from plspy_amd import operators, resample
+    from plspy_amd.engine import ProjectionEngine
+    co = np.array([[6] * 3, [5] * 3])
+    p = 3001
+    X = np.random.RandomState(2).randn(co.sum(), p)
+    W = operators.mean_centre_operator(co, 0)
+    Wm = operators.cell_mean_operator(co)
+    U, s, Vt = np.linalg.svd(W @ X, full_matrices=False)
+    M = W.T @ U
+    np.random.seed(7)
+    binds = resample.bootstraps(co, 50)
+    pinds = resample.task_permutations(co, 40)
+    outs = []
+    for overlap in (False, True):
+        eng = ProjectionEngine(X, work_limit=1 << 20)          # forces several batches
+        assert eng.batch_size(6, 6, 50) < 50
+        Xm = eng.apply_operator(Wm)
+        res = eng.boot_phase(6, inds=binds, M=M, ref=Vt.T * s, Xm=Xm, overlap_tail=overlap)
+        ssq = eng.perm_phase(6, inds=pinds, M=M)
+        eng.join()
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (res["S1"], res["S2"], res["ssq"], res["T"], ssq)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
