@@ -199,6 +199,33 @@ int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const doub
                 size_t work_bytes, void *stream);
 
 /*
+ * ---- K4f: fused gather / z-score / projection ---------------------------------
+ * Same result as plsr_gather_zscore followed by plsr_item_project, without the
+ * per-item matrix ever reaching HBM: a workgroup keeps X[:, 64 voxels] in LDS
+ * for all items, gathers rows through d_src, z-scores them on the fly from
+ * per-(item, cell, voxel) statistics (two-pass, computed by a first kernel from
+ * the same LDS tile) and multiplies by the item's operator rows.
+ *   d_src   : [items][nz] int32 source row of every row of the item matrix
+ *   cell_lo : HOST [ncell+1] row ranges of the cells, cell_z : HOST [ncell]
+ *             (1 = z-score the cell as class_functions.py:221-238, 0 = copy rows);
+ *             ncell <= 64
+ *   d_rows  : [items][k][nz] operator rows (VS_b = rows_b @ Z_b)
+ *   d_S1/d_S2 (both or neither): [p][k] += shifted moment sums (shift d_ref [p][k] or NULL)
+ *   d_vst   : [items][k][ldv] VS^T or NULL
+ *   d_rowsq : [items][ceil(k/16)*16]  sum_v VS_b[j][v]^2  or NULL
+ *             (bootstrap_permutation.py:623 norms; class_functions.py:503-505 row norms)
+ * k <= 128, n <= 320.
+ */
+size_t plsr_item_fused_workspace_bytes(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo,
+                                       int32_t ncell, int32_t items, int64_t p, int32_t want_moments,
+                                       int32_t want_rowsq);
+int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src,
+                    int32_t nz, const int32_t *cell_lo, const int32_t *cell_z, int32_t ncell,
+                    const double *d_rows, int32_t items, int32_t k, const double *d_ref, double *d_S1,
+                    double *d_S2, double *d_vst, int64_t ldv, double *d_rowsq, void *d_work,
+                    size_t work_bytes, void *stream);
+
+/*
  * ---- host: bit-exact NumPy legacy RandomState draws -------------------------
  * (no GPU involved; these run wherever the library loads).  key[624] / *pos are
  * np.random.get_state()[1:3]; they come back advanced so that

@@ -1,0 +1,360 @@
+// K4f: bootstrap of behaviour / multiblock PLS without materialising the
+// per-resample matrix.
+//
+// Every resample ("item") b has its own data matrix Z_b: rows of X gathered by
+// src_b and z-scored within output-row cells (class_functions.py:185-247),
+// and its own operator rows op_b (k x nz):
+//
+//     VS_b[j, v] = sum_i op_b[j, i] * Z_b[i, v],
+//     Z_b[i, v]  = X[src_b[i], v] * sc_b,c(v) + sh_b,c(v)      (i in cell c)
+//
+// with sc = 1 / (sd sqrt(n_c)), sh = -mean * sc for z-scored cells and
+// (1, 0) for copied cells.  A workgroup owns 64 voxels for ALL items of the
+// launch and keeps the whole X[:, tile] (n x 64) in LDS, so an item costs no
+// HBM traffic for X at all:
+//
+//   item_stats_kernel   two-pass mean / sd of the gathered rows per (item,
+//                       cell, voxel) from the LDS tile -> sc, sh
+//   item_meta_kernel    operator fragments (MFMA A operand, cells padded to
+//                       whole k-steps) and the LDS row offset of every (k-step,
+//                       lane group)
+//   item_fused_kernel   B operand = LDS row gathered through the offset table,
+//                       z-scored on the fly (one FMA), MFMA against the
+//                       operator fragments streamed from L2 through a register
+//                       ring.  One wave = one 16-row tile of latent variables x
+//                       NT 16-voxel tiles; waves never synchronise.  Epilogue
+//                       per item: shifted bootstrap moments in registers
+//                       (bootstrap_permutation.py:620-626, :695), VS^T for the
+//                       latent kernel, and the squared row norms of VS (:623).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "plsr_project.hip.h"
+
+namespace plsr {
+
+constexpr int FZ_MAXCELL = 64;
+
+struct FusedCells {
+  int32_t ncell, nkp;                  // cells, padded k-steps per item
+  int32_t row_lo[FZ_MAXCELL + 1];      // output-row range of every cell
+  int32_t step_lo[FZ_MAXCELL + 1];     // k-step range of every cell
+  int32_t z[FZ_MAXCELL];               // 1 = z-score, 0 = copy
+};
+
+// ---------------------------------------------------------------------------
+struct StatsArgs {
+  const double *X;
+  int64_t ldx, p;
+  int32_t n, nz, items;
+  const int32_t *src;                  // [items][nz]
+  FusedCells cells;
+  double *sc, *sh;                     // [items][ncell][p]
+};
+
+__global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t v0 = (int64_t)blockIdx.x * TV;
+  const int64_t v = v0 + lane;
+  for (int row = wave; row < A.n; row += WAVES)
+    smem[row * TV + lane] = v < A.p ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+  __syncthreads();
+  const int per = (A.items + gridDim.y - 1) / gridDim.y;
+  const int it_lo = blockIdx.y * per;
+  const int it_hi = min(A.items, it_lo + per);
+  const int ncell = A.cells.ncell;
+  // (item, cell) pairs round-robin over the four waves
+  for (int e = it_lo * ncell + wave; e < it_hi * ncell; e += WAVES) {
+    const int item = e / ncell;
+    const int c = e - item * ncell;
+    const int lo = A.cells.row_lo[c], hi = A.cells.row_lo[c + 1];
+    double sc = 1.0, sh = 0.0;
+    if (A.cells.z[c]) {
+      const int32_t *src = A.src + (int64_t)item * A.nz;
+      const double cnt = (double)(hi - lo);
+      // the cell's source rows, 64 at a time in one vector register (lane r holds
+      // row lo + r); v_readlane feeds the LDS address, so the row loop carries no
+      // memory latency of its own
+      double mu = 0.0;
+      for (int r0 = lo; r0 < hi; r0 += 64) {
+        const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
+        const int m = min(64, hi - r0);
+        for (int r = 0; r < m; ++r) mu += smem[__builtin_amdgcn_readlane(mine, r) + lane];
+      }
+      mu /= cnt;
+      double var = 0.0;
+      for (int r0 = lo; r0 < hi; r0 += 64) {
+        const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
+        const int m = min(64, hi - r0);
+        for (int r = 0; r < m; ++r) {
+          const double d = smem[__builtin_amdgcn_readlane(mine, r) + lane] - mu;
+          var = fma(d, d, var);
+        }
+      }
+      const double sd = sqrt(var / cnt);
+      // scipy.stats.zscore's constant-slice rule followed by nan_to_num -> 0
+      const bool dead = !(sd > 2.220446049250313e-16 * fabs(mu));
+      sc = dead ? 0.0 : 1.0 / (sd * sqrt(cnt));
+      sh = dead ? 0.0 : -mu * sc;
+    }
+    if (v < A.p) {
+      A.sc[(int64_t)e * A.p + v] = sc;
+      A.sh[(int64_t)e * A.p + v] = sh;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct MetaArgs {
+  const double *rows;                  // [items][k][nz] operator rows
+  const int32_t *src;                  // [items][nz]
+  int32_t items, k, nz, MC;
+  int32_t row_bytes;                   // bytes of one row of the fused kernel's LDS tile
+  FusedCells cells;
+  double *frag;                        // [MC][items][nkp][64]
+  int32_t *rowoff;                     // [items][nkp][4]  byte offset of the LDS row
+};
+
+__global__ __launch_bounds__(256) void item_meta_kernel(MetaArgs A) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nkp = A.cells.nkp;
+  const int64_t total = (int64_t)A.MC * A.items * nkp * 64;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  const int s = (int)((e >> 6) % nkp);
+  const int item = (int)(((e >> 6) / nkp) % A.items);
+  const int mc = (int)((e >> 6) / ((int64_t)nkp * A.items));
+  int c = 0;
+  while (c + 1 < A.cells.ncell && s >= A.cells.step_lo[c + 1]) ++c;
+  const int g = lane >> 4;
+  const int i = A.cells.row_lo[c] + 4 * (s - A.cells.step_lo[c]) + g;
+  const bool valid = i < A.cells.row_lo[c + 1];
+  const int j = mc * 16 + (lane & 15);
+  A.frag[e] = (valid && j < A.k) ? A.rows[((int64_t)item * A.k + j) * A.nz + i] : 0.0;
+  if (mc == 0 && (lane & 15) == 0) {
+    // padding rows point at the cell's first row (their operator entry is 0)
+    const int32_t row = A.src[(int64_t)item * A.nz + (valid ? i : A.cells.row_lo[c])];
+    A.rowoff[((int64_t)item * nkp + s) * 4 + g] = row * A.row_bytes;
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct FusedArgs {
+  const double *X;
+  int64_t ldx, p;
+  int32_t n, items, k, MC;
+  FusedCells cells;
+  const double *frag;                  // [MC][items][nkp][64] (+ 8 k-steps of padding)
+  const int32_t *rowoff;               // [items][nkp][4]      (+ 8 k-steps of padding)
+  const double *sc, *sh;               // [items][ncell][p]
+  const double *ref;                   // [p][k] shift of the moment sums, or null
+  double *S1, *S2;                     // [split][p][k] partial sums (overwritten), or null
+  double *vst;                         // [items][k][ldv] VS^T, or null
+  int64_t ldv;
+  double *rowsq_part;                  // [nvt * VB][items][MC*16] or null
+};
+
+// TVX = voxels per workgroup (LDS tile n x TVX), NT = 16-voxel tiles per wave;
+// the workgroup has MC * VB waves, VB = TVX / (16 NT) voxel blocks
+template <int NT, int TVX>
+__global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int VB = TVX / (16 * NT);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mc = wave % A.MC;
+  const int vb = wave / A.MC;
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int64_t v0 = (int64_t)blockIdx.x * TVX;
+
+  // ---- the whole X[:, tile] stays in LDS for the life of the workgroup ----
+  for (int e = tid; e < A.n * TVX; e += blockDim.x) {
+    const int row = e / TVX;
+    const int64_t v = v0 + (e % TVX);
+    smem[e] = v < A.p ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+  }
+  __syncthreads();
+  const char *Xb = (const char *)smem + ((vb * NT) * 16 + col) * 8;   // + rowoff + nt*128
+
+  const int per = (A.items + gridDim.y - 1) / gridDim.y;
+  const int it_lo = blockIdx.y * per;
+  const int it_hi = min(A.items, it_lo + per);
+  if (it_lo >= it_hi) return;
+  const int nkp = A.cells.nkp;
+  const int ncell = A.cells.ncell;
+
+  int64_t vox[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) vox[nt] = v0 + (vb * NT + nt) * 16 + col;
+
+  double s1[NT][4], s2[NT][4], rf[NT][4];
+  const bool moments = A.S1 != nullptr;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = mc * 16 + g + 4 * r;
+      s1[nt][r] = 0.0;
+      s2[nt][r] = 0.0;
+      rf[nt][r] = (A.ref != nullptr && j < A.k && vox[nt] < A.p) ? A.ref[vox[nt] * A.k + j] : 0.0;
+    }
+
+  // Stream of k-steps over (item, cell, step): fragments and row offsets are
+  // contiguous per wave, so the 4-deep register rings run on across cell and
+  // item boundaries.  The k-loops hold no memory operation besides the rings
+  // (the scale / shift of a cell are prefetched one cell ahead, between loops).
+  const double *fp = A.frag + ((size_t)mc * A.items * nkp + (size_t)it_lo * nkp) * 64 + lane;
+  const int32_t *rp = A.rowoff + ((size_t)it_lo * nkp) * 4 + g;
+  double ra[4];
+  int ro[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    ra[u] = fp[(size_t)u * 64];
+    ro[u] = rp[u * 4];
+  }
+  double bn[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + ro[0] + nt * 128);
+
+  // Unconditional loads (clamped addresses): a select on the loaded value would
+  // make the prefetch wait for its own data.  Lanes past p read voxel p-1 and
+  // are masked where results leave the kernel.
+  int64_t voxc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) voxc[nt] = min(vox[nt], A.p - 1);
+  auto load_cell = [&](int item, int c, double (&sc)[NT], double (&sh)[NT]) {
+    const int64_t base = ((int64_t)min(item, it_hi - 1) * ncell + c) * A.p;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      sc[nt] = A.sc[base + voxc[nt]];
+      sh[nt] = A.sh[base + voxc[nt]];
+    }
+  };
+
+  double sc[NT], sh[NT], scn[NT], shn[NT];
+  load_cell(it_lo, 0, scn, shn);
+
+  f64x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  int64_t pos = 0;                       // stream position of the current cell's first step
+  int phase = 0;                         // ring slot of that step
+  for (int item = it_lo; item < it_hi; ++item) {
+    for (int c = 0; c < ncell; ++c) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        sc[nt] = scn[nt];
+        sh[nt] = shn[nt];
+      }
+      {
+        const bool last = c + 1 == ncell;
+        load_cell(last ? item + 1 : item, last ? 0 : c + 1, scn, shn);
+      }
+      const int ns = A.cells.step_lo[c + 1] - A.cells.step_lo[c];
+      const double *fq = fp + (size_t)pos * 64;
+      const int32_t *rq = rp + pos * 4;
+
+      // one k-step: uses ring slot u, reads the raw rows of the next step
+      // through ring slot un, refills slot u four steps ahead
+      auto step = [&](int sidx, int u, int un) {
+        double z[NT];
+#pragma unroll
+#if PLSR_ABLATE & 512
+        for (int nt = 0; nt < NT; ++nt) z[nt] = bn[nt];
+#else
+        for (int nt = 0; nt < NT; ++nt) z[nt] = fma(bn[nt], sc[nt], sh[nt]);
+#endif
+        const int ron = ro[un];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + ron + nt * 128);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(ra[u], z[nt], acc[nt]);
+        ra[u] = fq[(size_t)(sidx + 4) * 64];
+        ro[u] = rq[(sidx + 4) * 4];
+      };
+
+      // A cell rarely has a multiple of four steps, so the ring slot of its first
+      // step ("phase") moves from cell to cell.  Rotating the ring registers would
+      // need every outstanding load back (s_waitcnt vmcnt(0) once per cell);
+      // instead the loop exists in four variants with static slot numbers.
+      auto run = [&](auto ph) {
+        constexpr int P = decltype(ph)::value;
+        int s = 0;
+        for (; s + 4 <= ns; s += 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) step(s + u, (P + u) & 3, (P + u + 1) & 3);
+        }
+        const int rem = ns & 3;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (u < rem) step(s + u, (P + u) & 3, (P + u + 1) & 3);
+      };
+      switch (phase) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        default: run(std::integral_constant<int, 3>{}); break;
+      }
+      phase = (phase + ns) & 3;
+      pos += ns;
+    }
+
+    // ---- item done: acc[nt][r] = VS[j = 16 mc + g + 4 r][voxel nt] ----
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = mc * 16 + g + 4 * r;
+        const double val = acc[nt][r];
+        if (moments) {
+          const double d = val - rf[nt][r];
+          s1[nt][r] += d;
+          s2[nt][r] = fma(d, d, s2[nt][r]);
+        }
+        if (vox[nt] < A.p) q[r] = fma(val, val, q[r]);
+        if (A.vst != nullptr && j < A.k && vox[nt] < A.p)
+          A.vst[((int64_t)item * A.k + j) * A.ldv + vox[nt]] = val;
+        acc[nt][r] = 0.0;
+      }
+    if (A.rowsq_part != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double x = q[r];
+        x += __shfl_xor(x, 1);
+        x += __shfl_xor(x, 2);
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        if (col == 0)
+          A.rowsq_part[(((int64_t)blockIdx.x * VB + vb) * A.items + item) * (A.MC * 16) + mc * 16 + g + 4 * r] = x;
+      }
+    }
+  }
+
+  if (moments) {
+    double *o1 = A.S1 + (int64_t)blockIdx.y * A.p * A.k;
+    double *o2 = A.S2 + (int64_t)blockIdx.y * A.p * A.k;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = mc * 16 + g + 4 * r;
+        if (j < A.k && vox[nt] < A.p) {
+          o1[vox[nt] * A.k + j] = s1[nt][r];
+          o2[vox[nt] * A.k + j] = s2[nt][r];
+        }
+      }
+  }
+}
+
+}  // namespace plsr

@@ -2,9 +2,11 @@
 // the bootstrap of behaviour / multiblock PLS.  See include/plsr.h.
 #include "../../include/plsr.h"
 #include "plsr_item.hip.h"
+#include "plsr_fused.hip.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 using namespace plsr;
 
@@ -165,5 +167,196 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
                      (const double *)a.Zt_part, d_Zt, EZ, pl.nchunk, pl.nchunk);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
                      (const double *)a.nsq_part, d_nsq, EN, pl.nchunk, pl.nchunk);
+  return launch_ok();
+}
+
+// ---------------------------------------------------------------------------
+// K4f: fused gather / z-score / projection (plsr_fused.hip.h)
+// ---------------------------------------------------------------------------
+namespace {
+struct FusedPlan {
+  FusedCells cells;
+  int MC, NT, TVX, VB, waves, nsplit, nchunk;
+  int64_t nvt, nslab;
+  size_t lds;
+  // workspace carve (byte offsets)
+  size_t o_frag, o_rowoff, o_sc, o_sh, o_mom, o_sq, o_sq2, bytes;
+};
+
+bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const int32_t *cell_z,
+                int32_t ncell, int32_t items, int64_t p, bool moments, bool rowsq, FusedPlan &pl) {
+  if (n <= 0 || nz <= 0 || k <= 0 || items <= 0 || p <= 0 || !cell_lo || ncell <= 0 || ncell > FZ_MAXCELL)
+    return false;
+  if (cell_lo[0] != 0 || cell_lo[ncell] != nz) return false;
+  pl.MC = (k + 15) / 16;
+  if (pl.MC > 8) return false;
+  // One wave = one 16-row tile of latent variables x NT 16-voxel tiles.  With
+  // three or more tiles of latent variables a 32-voxel workgroup (NT = 2) keeps
+  // the LDS tile small enough for 4-5 resident workgroups per CU; the waves hide
+  // each other's store / load latency (they never synchronise).
+  if (pl.MC >= 3) {
+    pl.TVX = 32;
+    pl.NT = 2;
+  } else {
+    pl.TVX = 64;
+    pl.NT = pl.MC;          // 1 or 2
+  }
+  if (const char *e = getenv("PLSR_FUSED_WIDE")) {   // developer switch: 64-voxel workgroups, NT = 4
+    if (e[0] == '1' && pl.MC >= 3) {
+      pl.TVX = 64;
+      pl.NT = 4;
+    }
+    if (e[0] == '2' && pl.MC >= 3) {                  // 64 voxels as two blocks of NT = 2
+      pl.TVX = 64;
+      pl.NT = 2;
+    }
+  }
+  pl.VB = pl.TVX / (16 * pl.NT);
+  pl.waves = pl.MC * pl.VB;
+  pl.lds = (size_t)n * pl.TVX * sizeof(double);
+  if (pl.lds > 160 * 1024) return false;
+  pl.cells.ncell = ncell;
+  int steps = 0;
+  for (int c = 0; c < ncell; ++c) {
+    if (cell_lo[c + 1] <= cell_lo[c]) return false;
+    pl.cells.row_lo[c] = cell_lo[c];
+    pl.cells.step_lo[c] = steps;
+    pl.cells.z[c] = cell_z ? cell_z[c] : 1;
+    steps += (cell_lo[c + 1] - cell_lo[c] + 3) / 4;
+  }
+  pl.cells.row_lo[ncell] = cell_lo[ncell];
+  pl.cells.step_lo[ncell] = steps;
+  pl.cells.nkp = steps;
+  pl.nvt = (p + pl.TVX - 1) / pl.TVX;
+  pl.nsplit = (int)std::min<int64_t>(items, std::max<int64_t>(1, (1024 + pl.nvt - 1) / pl.nvt));
+  pl.nslab = pl.nvt * pl.VB;
+  pl.nchunk = (int)((pl.nslab + 63) / 64);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t E = (size_t)items * pl.MC * 16;
+  pl.o_frag = take(((size_t)pl.MC * items * steps + 8) * 64 * sizeof(double));
+  pl.o_rowoff = take(((size_t)items * steps + 8) * 4 * sizeof(int32_t));
+  pl.o_sc = take((size_t)items * ncell * p * sizeof(double));
+  pl.o_sh = take((size_t)items * ncell * p * sizeof(double));
+  pl.o_mom = take(moments ? (size_t)2 * pl.nsplit * p * k * sizeof(double) : 0);
+  pl.o_sq = take(rowsq ? (size_t)pl.nslab * E * sizeof(double) : 0);
+  pl.o_sq2 = take(rowsq ? (size_t)pl.nchunk * E * sizeof(double) : 0);
+  pl.bytes = off;
+  return true;
+}
+
+template <int NT, int TVX>
+int run_fused(const FusedArgs &a, const FusedPlan &pl, hipStream_t st) {
+  auto kern = item_fused_kernel<NT, TVX>;
+  if (pl.lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+    return PLSR_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)pl.nvt, (unsigned)pl.nsplit), dim3(pl.waves * 64), pl.lds, st, a);
+  return launch_ok();
+}
+}  // namespace
+
+extern "C" size_t plsr_item_fused_workspace_bytes(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo,
+                                                  int32_t ncell, int32_t items, int64_t p,
+                                                  int32_t want_moments, int32_t want_rowsq) {
+  FusedPlan pl;
+  return fused_plan(n, nz, k, cell_lo, nullptr, ncell, items, p, want_moments != 0, want_rowsq != 0, pl)
+             ? pl.bytes
+             : 0;
+}
+
+extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src,
+                               int32_t nz, const int32_t *cell_lo, const int32_t *cell_z, int32_t ncell,
+                               const double *d_rows, int32_t items, int32_t k, const double *d_ref,
+                               double *d_S1, double *d_S2, double *d_vst, int64_t ldv, double *d_rowsq,
+                               void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_src || !d_rows || !d_work || !cell_lo || !cell_z || ldx < p) return PLSR_EINVAL;
+  if ((d_S1 == nullptr) != (d_S2 == nullptr) || (d_vst && ldv < p)) return PLSR_EINVAL;
+  FusedPlan pl;
+  if (!fused_plan(n, nz, k, cell_lo, cell_z, ncell, items, p, d_S1 != nullptr, d_rowsq != nullptr, pl))
+    return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char *w = (char *)d_work;
+
+  StatsArgs sa;
+  sa.X = d_X;
+  sa.ldx = ldx;
+  sa.p = p;
+  sa.n = n;
+  sa.nz = nz;
+  sa.items = items;
+  sa.src = d_src;
+  sa.cells = pl.cells;
+  sa.sc = (double *)(w + pl.o_sc);
+  sa.sh = (double *)(w + pl.o_sh);
+  const size_t lds_stats = (size_t)n * TV * sizeof(double);
+  if (lds_stats > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)item_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_stats) != hipSuccess)
+    return PLSR_ELAUNCH;
+  hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)((p + TV - 1) / TV), (unsigned)pl.nsplit), dim3(256),
+                     lds_stats, st, sa);
+
+  MetaArgs ma;
+  ma.rows = d_rows;
+  ma.src = d_src;
+  ma.items = items;
+  ma.k = k;
+  ma.nz = nz;
+  ma.MC = pl.MC;
+  ma.row_bytes = pl.TVX * 8;
+  ma.cells = pl.cells;
+  ma.frag = (double *)(w + pl.o_frag);
+  ma.rowoff = (int32_t *)(w + pl.o_rowoff);
+  const int64_t total = (int64_t)pl.MC * items * pl.cells.nkp * 64;
+  // the prefetch rings run 8 k-steps past the end: keep that padding defined
+  (void)hipMemsetAsync(ma.frag + total, 0, 8 * 64 * sizeof(double), st);
+  (void)hipMemsetAsync(ma.rowoff + (size_t)items * pl.cells.nkp * 4, 0, 8 * 4 * sizeof(int32_t), st);
+  hipLaunchKernelGGL(item_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ma);
+
+  FusedArgs a;
+  a.X = d_X;
+  a.ldx = ldx;
+  a.p = p;
+  a.n = n;
+  a.items = items;
+  a.k = k;
+  a.MC = pl.MC;
+  a.cells = pl.cells;
+  a.frag = ma.frag;
+  a.rowoff = ma.rowoff;
+  a.sc = sa.sc;
+  a.sh = sa.sh;
+  a.ref = d_ref;
+  a.S1 = d_S1 ? (double *)(w + pl.o_mom) : nullptr;
+  a.S2 = d_S1 ? a.S1 + (size_t)pl.nsplit * p * k : nullptr;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  a.rowsq_part = d_rowsq ? (double *)(w + pl.o_sq) : nullptr;
+  int rc = PLSR_EUNSUPPORTED;
+  if (pl.TVX == 32 && pl.NT == 2) rc = run_fused<2, 32>(a, pl, st);
+  if (pl.TVX == 64 && pl.NT == 1) rc = run_fused<1, 64>(a, pl, st);
+  if (pl.TVX == 64 && pl.NT == 2) rc = run_fused<2, 64>(a, pl, st);
+  if (pl.TVX == 64 && pl.NT == 4) rc = run_fused<4, 64>(a, pl, st);
+  if (rc) return rc;
+  if (d_S1) {
+    const int64_t cnt = p * k;
+    dim3 g((unsigned)((cnt + 255) / 256));
+    hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S1, (const double *)a.S1, cnt, pl.nsplit);
+    hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S2, (const double *)a.S2, cnt, pl.nsplit);
+  }
+  if (d_rowsq) {
+    const int64_t E = (int64_t)items * pl.MC * 16;
+    double *lvl2 = (double *)(w + pl.o_sq2);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)pl.nchunk), dim3(256), 0, st,
+                       (const double *)a.rowsq_part, lvl2, E, (int)pl.nslab, 64);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
+                       (const double *)lvl2, d_rowsq, E, pl.nchunk, pl.nchunk);
+  }
   return launch_ok();
 }

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #ifndef PLSR_ABLATE
 #define PLSR_ABLATE 0   // developer-only timing ablations (wrong results when non-zero)
 #endif
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
   // a fragment load is always covered by 16 MFMAs.  `bn` holds the X fragments
   // (B operand, from LDS) one k-step ahead.  The loop body has no branches.
   double ring[4];
+  int phase = 0;              // ring slot holding the current tile's first k-step
   double bn[NT];
   {
     const double *ap0 = A.frag + ((size_t)w_lo * nk) * 64 + lane;
@@ -217,27 +220,37 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
 #endif
       };
 
-      int s = 0;
-      for (; s + 4 <= nk; s += 4) {
+      // nk is rarely a multiple of four, so the ring slot of a tile's first k-step
+      // ("phase") moves from tile to tile.  Rotating the ring registers back would
+      // need every outstanding fragment load returned (s_waitcnt vmcnt(0) once per
+      // tile); instead the k-loop exists in four variants with static slot numbers.
+      auto kloop = [&](auto ph) {
+        constexpr int P = decltype(ph)::value;
+        int s = 0;
+        for (; s + 4 <= nk; s += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // refill the slot after the MFMAs that read it have been issued: the load
-          // can then target the same register (no end-of-chunk copies / vmcnt(0))
-          step(s + u, ring[u]);
-          ring[u] = fetch(s + u + 4);
+          for (int u = 0; u < 4; ++u) {
+            // refill the slot after the MFMAs that read it have been issued: the
+            // load can then target the same register
+            step(s + u, ring[(P + u) & 3]);
+            ring[(P + u) & 3] = fetch(s + u + 4);
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        if (u < rem) {
-          step(s + u, ring[u]);
-          ring[u] = fetch(s + u + 4);
+        for (int u = 0; u < 3; ++u) {
+          if (u < rem) {
+            step(s + u, ring[(P + u) & 3]);
+            ring[(P + u) & 3] = fetch(s + u + 4);
+          }
         }
+      };
+      switch (phase) {
+        case 0: kloop(std::integral_constant<int, 0>{}); break;
+        case 1: kloop(std::integral_constant<int, 1>{}); break;
+        case 2: kloop(std::integral_constant<int, 2>{}); break;
+        default: kloop(std::integral_constant<int, 3>{}); break;
       }
-      // the ring now starts `rem` slots in: rotate it back so slot u = next tile's k-step u
-      if (rem == 1) { const double x = ring[0]; ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3]; ring[3] = x; }
-      if (rem == 2) { double x = ring[0]; ring[0] = ring[2]; ring[2] = x; x = ring[1]; ring[1] = ring[3]; ring[3] = x; }
-      if (rem == 3) { const double x = ring[3]; ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = x; }
+      phase = (phase + rem) & 3;
 
       // quad / resample bookkeeping of this lane group
       const int q = 4 * t + g;

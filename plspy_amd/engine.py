@@ -270,6 +270,34 @@ class ProjectionEngine:
                                             _ptr(G), _ptr(work), need, _stream()), "plsr_gram_batch")
         return G
 
+    def item_fused(self, src, cell_lo, cell_z, rows, ref=None, S1=None, S2=None, want_vst=False,
+                   want_rowsq=False):
+        """K4f: VS_b = rows_b @ Z_b for every item without materialising Z_b
+        (Z_b = X[src_b] z-scored within the cells flagged in cell_z).
+        rows (items, k, nz).  S1 / S2 (p, k) are accumulated into when given.
+        Returns (vst (items, k, p) or None, rowsq (items, k) or None)."""
+        d_src = self.dev(src, torch.int32)
+        d_rows = self.dev(rows)
+        items, k, nz = d_rows.shape
+        assert d_src.shape == (items, nz)
+        lo = (ctypes.c_int32 * (len(cell_lo)))(*[int(x) for x in cell_lo])
+        zf = (ctypes.c_int32 * (len(cell_z)))(*[int(x) for x in cell_z])
+        ncell = len(cell_z)
+        need = self.lib.plsr_item_fused_workspace_bytes(self.n, nz, k, lo, ncell, items, self.p,
+                                                        int(S1 is not None), int(want_rowsq))
+        if need == 0:
+            raise _lib.PlsrError(f"plsr_item_fused: unsupported shape n={self.n} nz={nz} k={k} ncell={ncell}")
+        work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        refd = self.dev(ref)
+        vst = torch.empty((items, k, self.p), dtype=torch.float64, device=self.device) if want_vst else None
+        k16 = (k + 15) // 16 * 16
+        rowsq = torch.empty((items, k16), dtype=torch.float64, device=self.device) if want_rowsq else None
+        _lib.check(self.lib.plsr_item_fused(
+            _ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_src), nz, lo, zf, ncell, _ptr(d_rows),
+            items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p, _ptr(rowsq), _ptr(work), need,
+            _stream()), "plsr_item_fused")
+        return vst, (rowsq[:, :k] if want_rowsq else None)
+
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
@@ -290,38 +318,31 @@ class ProjectionEngine:
         S2 = torch.zeros_like(S1)
         Zt = torch.empty((R, k, n), dtype=torch.float64, device=self.device)
         nsq = torch.empty((R, k), dtype=torch.float64, device=self.device)
-        per_item = (nz + k) * self.p * 8 + 2 * k * nz * 8
+        ncell = len(cell_z)
+        per_item = (2 * ncell + k + 4) * self.p * 8 + 2 * k * nz * 8
         step = int(max(1, min(R, (self.work_limit // 2) // per_item)))
         for lo in range(0, R, step):
             hi = min(R, lo + step)
             cnt = hi - lo
-            Z = self.gather_zscore(src[lo:hi], cell_lo, cell_z)                  # (cnt, nz, p)
+            d_src = self.dev(src[lo:hi], torch.int32)
             rownorm = None
             if raw_rows_fn is not None:
+                # two-phase row normalisation of the multiblock (class_functions.py:503-505):
+                # norms over all voxels of the un-normalised rows, K4f in norms-only mode
                 raw = np.ascontiguousarray(raw_rows_fn(lo, hi), dtype=np.float64)
-                G = self._gram_of_items(Z, raw)
-                m = raw.shape[1]
-                rownorm = np.sqrt(torch.diagonal(G, dim1=1, dim2=2)[:, :m].cpu().numpy())
+                _, rsq = self.item_fused(d_src, cell_lo, cell_z, raw, want_rowsq=True)
+                rownorm = np.sqrt(rsq.cpu().numpy())
             ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
-            d_ops = self.dev(ops)
-            frag = torch.empty(self.lib.plsr_rows_frag_elems(nz, k, cnt), dtype=torch.float64,
-                               device=self.device)
-            _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_ops), cnt, k, nz, _ptr(frag), _stream()),
-                       "plsr_ops_pack_rows")
-            vst = torch.empty((cnt, k, self.p), dtype=torch.float64, device=self.device)
-            need = self.lib.plsr_item_workspace_bytes(nz, k, cnt, self.p)
-            if need == 0:
-                raise _lib.PlsrError(f"plsr_item_project: unsupported shape n={nz} k={k}")
-            work = torch.empty(need, dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.plsr_item_project(_ptr(Z), Z.stride(0), Z.stride(1), self.p, nz, _ptr(frag),
-                                                  cnt, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p,
-                                                  _ptr(work), need, _stream()), "plsr_item_project")
+            vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
+                                       want_rowsq=True)
+            nsq[lo:hi] = rsq
             need2 = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
             if need2 == 0:
                 raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
             work2 = torch.empty(need2, dtype=torch.uint8, device=self.device)
+            nsq2 = torch.empty((cnt, k), dtype=torch.float64, device=self.device)
             _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
-                                            k, _ptr(Zt[lo:hi]), _ptr(nsq[lo:hi]), _ptr(work2), need2,
+                                            k, _ptr(Zt[lo:hi]), _ptr(nsq2), _ptr(work2), need2,
                                             _stream()), "plsr_latent")
         return {"S1": S1, "S2": S2, "Zt": Zt, "nsq": nsq, "R": R}
 

@@ -208,3 +208,56 @@ def test_split_half_rb_mb(name):
     for key, val in res.items():
         if not key.startswith("pls_dist"):
             assert_close(np.array(val)[:lv], fx["sh_" + key][:lv], 1e-5, 1e-9, key)
+
+
+@pytest.mark.parametrize("shape", [
+    # (n, p, cells (row counts), z flags, k, items)
+    (24, 130, (6, 5, 7, 6), (1, 1, 1, 1), 5, 7),          # ragged cells, k < 16, voxels off the tile
+    (40, 257, (40, 12, 9, 11), (0, 1, 1, 1), 20, 5),      # copy cell + z cells (multiblock layout), 2 LV tiles
+    (30, 64, (10, 10, 10), (1, 1, 1), 48, 9),             # 3 LV tiles
+    (21, 70, (21,), (1,), 70, 3),                         # one cell, 5 LV tiles
+])
+def test_fused_items_match_gather_then_project(shape):
+    """K4f (gather + z-score + projection in one pass over an LDS-resident X
+    tile) against the NumPy statement of the same thing and against the
+    two-kernel path (plsr_gather_zscore + dense product)."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    n, p, cells, zflags, k, items = shape
+    rs = np.random.RandomState(n + p)
+    X = rs.randn(n, p) * 3 + rs.randn(1, p) * 50 + 100
+    X[:, 3] = 7.0                                     # a constant voxel -> z cells give 0
+    nz = sum(cells)
+    cell_lo = np.concatenate(([0], np.cumsum(cells)))
+    src = rs.randint(0, n, size=(items, nz)).astype(np.int32)
+    rows = rs.randn(items, k, nz)
+    ref = rs.randn(p, k)
+    eng = ProjectionEngine(X)
+    S1 = torch.zeros((p, k), dtype=torch.float64, device=eng.device)
+    S2 = torch.zeros_like(S1)
+    vst, rowsq = eng.item_fused(src, cell_lo, zflags, rows, ref=ref, S1=S1, S2=S2, want_vst=True,
+                                want_rowsq=True)
+    Z = eng.gather_zscore(src, cell_lo, zflags).cpu().numpy()       # (items, nz, p), K3
+    # NumPy statement
+    Zn = np.empty((items, nz, p))
+    for b in range(items):
+        G = X[src[b]]
+        for c, (lo, hi) in enumerate(zip(cell_lo[:-1], cell_lo[1:])):
+            if zflags[c]:
+                blk = G[lo:hi]
+                mu, sd = blk.mean(0), blk.std(0)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    z = (blk - mu) / sd / np.sqrt(hi - lo)
+                z[:, sd <= 2.220446049250313e-16 * np.abs(mu)] = 0.0
+                Zn[b, lo:hi] = z
+            else:
+                Zn[b, lo:hi] = G[lo:hi]
+    np.testing.assert_allclose(Z, Zn, rtol=1e-9, atol=1e-12)
+    want = np.einsum("bji,biv->bjv", rows, Zn)
+    got = vst.cpu().numpy()
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(rowsq.cpu().numpy(), (want ** 2).sum(-1), rtol=1e-10)
+    d = np.transpose(want, (0, 2, 1)) - ref
+    np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-9, atol=1e-10 * scale)
+    np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-10 * scale ** 2)
