@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
       for (int r0 = lo; r0 < hi; r0 += 64) {
         const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
         const int m = min(64, hi - r0);
+#pragma unroll 8
         for (int r = 0; r < m; ++r) mu += smem[__builtin_amdgcn_readlane(mine, r) + lane];
       }
       mu /= cnt;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
       for (int r0 = lo; r0 < hi; r0 += 64) {
         const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
         const int m = min(64, hi - r0);
+#pragma unroll 8
         for (int r = 0; r < m; ++r) {
           const double d = smem[__builtin_amdgcn_readlane(mine, r) + lane] - mu;
           var = fma(d, d, var);
@@ -191,20 +193,24 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   const int nkp = A.cells.nkp;
   const int ncell = A.cells.ncell;
 
-  int64_t vox[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) vox[nt] = v0 + (vb * NT + nt) * 16 + col;
+  // voxel of tile nt = vbase + 16 nt (kept as one register, not NT of them)
+  const int64_t vbase = v0 + vb * NT * 16 + col;
+  struct {
+    int64_t b;
+    __device__ int64_t operator[](int nt) const { return b + 16 * nt; }
+  } vox{vbase};
 
-  double s1[NT][4], s2[NT][4], rf[NT][4];
+  // plain sums over this workgroup's items; the shift by the observed VS is
+  // applied when the partials are merged (moment_unshift_kernel) -- keeping the
+  // shift in registers here would push the NT = 4 instance into scratch
+  double s1[NT][4], s2[NT][4];
   const bool moments = A.S1 != nullptr;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = mc * 16 + g + 4 * r;
       s1[nt][r] = 0.0;
       s2[nt][r] = 0.0;
-      rf[nt][r] = (A.ref != nullptr && j < A.k && vox[nt] < A.p) ? A.ref[vox[nt] * A.k + j] : 0.0;
     }
 
   // Stream of k-steps over (item, cell, step): fragments and row offsets are
@@ -227,15 +233,13 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   // Unconditional loads (clamped addresses): a select on the loaded value would
   // make the prefetch wait for its own data.  Lanes past p read voxel p-1 and
   // are masked where results leave the kernel.
-  int64_t voxc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) voxc[nt] = min(vox[nt], A.p - 1);
   auto load_cell = [&](int item, int c, double (&sc)[NT], double (&sh)[NT]) {
     const int64_t base = ((int64_t)min(item, it_hi - 1) * ncell + c) * A.p;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      sc[nt] = A.sc[base + voxc[nt]];
-      sh[nt] = A.sh[base + voxc[nt]];
+      const int64_t vc = min(vox[nt], A.p - 1);
+      sc[nt] = A.sc[base + vc];
+      sh[nt] = A.sh[base + vc];
     }
   };
 
@@ -318,9 +322,8 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
         const int j = mc * 16 + g + 4 * r;
         const double val = acc[nt][r];
         if (moments) {
-          const double d = val - rf[nt][r];
-          s1[nt][r] += d;
-          s2[nt][r] = fma(d, d, s2[nt][r]);
+          s1[nt][r] += val;
+          s2[nt][r] = fma(val, val, s2[nt][r]);
         }
         if (vox[nt] < A.p) q[r] = fma(val, val, q[r]);
         if (A.vst != nullptr && j < A.k && vox[nt] < A.p)
@@ -355,6 +358,25 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
         }
       }
   }
+}
+
+// S1 += sum_b (x_b - ref),  S2 += sum_b (x_b - ref)^2  from the plain partial
+// sums  P1 = sum x_b,  P2 = sum x_b^2  of `items` resamples (fixed split order).
+// The expansion loses eps * mean^2 / var relative accuracy, the same as the
+// final variance formula (boot_finalize_kernel) does anyway.
+__global__ __launch_bounds__(256) void moment_unshift_kernel(double *S1, double *S2, const double *P1,
+                                                            const double *P2, const double *ref,
+                                                            int64_t count, int nsplit, double items) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  double a = P1[e], b = P2[e];
+  for (int c = 1; c < nsplit; ++c) {
+    a += P1[(int64_t)c * count + e];
+    b += P2[(int64_t)c * count + e];
+  }
+  const double r = ref != nullptr ? ref[e] : 0.0;
+  S1[e] += a - items * r;
+  S2[e] += fma(r, fma(items, r, -2.0 * a), b);
 }
 
 }  // namespace plsr

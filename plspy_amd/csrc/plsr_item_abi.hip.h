@@ -190,24 +190,16 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   if (cell_lo[0] != 0 || cell_lo[ncell] != nz) return false;
   pl.MC = (k + 15) / 16;
   if (pl.MC > 8) return false;
-  // One wave = one 16-row tile of latent variables x NT 16-voxel tiles.  With
-  // three or more tiles of latent variables a 32-voxel workgroup (NT = 2) keeps
-  // the LDS tile small enough for 4-5 resident workgroups per CU; the waves hide
-  // each other's store / load latency (they never synchronise).
-  if (pl.MC >= 3) {
-    pl.TVX = 32;
-    pl.NT = 2;
-  } else {
-    pl.TVX = 64;
-    pl.NT = pl.MC;          // 1 or 2
-  }
-  if (const char *e = getenv("PLSR_FUSED_WIDE")) {   // developer switch: 64-voxel workgroups, NT = 4
+  // One wave = one 16-row tile of latent variables x NT 16-voxel tiles; a
+  // fragment load feeds NT MFMAs, so NT = 4 keeps the L2 traffic at the level of
+  // the projection kernel.  (Measured at config 3, k = 48: 64-voxel workgroups
+  // of three NT = 4 waves beat 32-voxel ones with NT = 2 at five per CU, whose
+  // vector L1 stalls on twice the fragment traffic.)
+  pl.TVX = 64;
+  pl.NT = pl.MC >= 3 ? 4 : pl.MC;
+  if (const char *e = getenv("PLSR_FUSED_NARROW")) {   // developer switch: 32-voxel workgroups, NT = 2
     if (e[0] == '1' && pl.MC >= 3) {
-      pl.TVX = 64;
-      pl.NT = 4;
-    }
-    if (e[0] == '2' && pl.MC >= 3) {                  // 64 voxels as two blocks of NT = 2
-      pl.TVX = 64;
+      pl.TVX = 32;
       pl.NT = 2;
     }
   }
@@ -347,8 +339,8 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   if (d_S1) {
     const int64_t cnt = p * k;
     dim3 g((unsigned)((cnt + 255) / 256));
-    hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S1, (const double *)a.S1, cnt, pl.nsplit);
-    hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S2, (const double *)a.S2, cnt, pl.nsplit);
+    hipLaunchKernelGGL(moment_unshift_kernel, g, dim3(256), 0, st, d_S1, d_S2, (const double *)a.S1,
+                       (const double *)a.S2, d_ref, cnt, pl.nsplit, (double)items);
   }
   if (d_rowsq) {
     const int64_t E = (int64_t)items * pl.MC * 16;
