@@ -1,11 +1,10 @@
 """Sharding of resample ids over the GPUs of one node (one process per GPU).
 
 Resamples are independent, so the only exchange is one collective per phase
-(RCCL over xGMI; gloo in the CPU tests): every rank contributes one packed
-fp64 buffer -- its per-resample results (s_hat^2, Tdistrib numerators) and,
-for the bootstrap, its shifted moment sums -- and receives everybody's.
-Per-resample rows are concatenated in rank order; moment sums are added in
-rank order, so every rank ends with bit-identical results.
+(RCCL over xGMI; gloo in the CPU tests): an all_gather of the per-resample
+results (s_hat^2, Tdistrib numerators; rows concatenated in rank order) and,
+for the bootstrap, an all_reduce of the shifted moment sums.  Every rank ends
+with bit-identical results.
 
 Index vectors are drawn once, on rank 0, in the reference's RNG order and
 broadcast, so results do not depend on the number of GPUs."""
@@ -43,11 +42,15 @@ def broadcast_indices(inds, device=None):
 
 
 def exchange(per_resample, summed, R):
-    """One all_gather per phase.
+    """The collectives of one phase: an all_gather of the ranks' per-resample
+    rows (small) and an all_reduce of the moment sums (2 p k doubles; an
+    all_gather of those would move world_size times the data over xGMI).
 
     per_resample: list of tensors whose dim 0 is this rank's resample block.
     summed:       list of tensors to be added over ranks (moment sums).
-    Returns (list of full per-resample tensors, list of rank-ordered sums)."""
+    Returns (list of full per-resample tensors, list of summed tensors); every
+    rank ends with bit-identical results (RCCL / gloo reduce each element along
+    one path and broadcast it)."""
     rank, n = world()
     if n == 1:
         return per_resample, summed
@@ -55,33 +58,30 @@ def exchange(per_resample, summed, R):
     # RCCL moves device buffers over xGMI directly; any other backend (gloo in
     # the CPU tests) is staged through host memory
     dev = out_dev if td.get_backend() == "nccl" else torch.device("cpu")
-    bounds = [shard_bounds(R, r, n) for r in range(n)]
-    maxrows = max(hi - lo for lo, hi in bounds)
-    row_elems = [int(np.prod(t.shape[1:])) for t in per_resample]
-    sum_elems = [t.numel() for t in summed]
-    width = maxrows * sum(row_elems) + sum(sum_elems)
-    send = torch.zeros(width, dtype=torch.float64, device=dev)
-    off = 0
-    for t, re in zip(per_resample, row_elems):
-        send[off:off + t.numel()] = t.reshape(-1).to(dev)
-        off += maxrows * re
-    for t, se in zip(summed, sum_elems):
-        send[off:off + se] = t.reshape(-1).to(dev)
-        off += se
-    recv = [torch.empty_like(send) for _ in range(n)]
-    td.all_gather(recv, send)
     full = []
-    off = 0
-    for t, re in zip(per_resample, row_elems):
-        parts = [recv[r][off:off + (hi - lo) * re].reshape((hi - lo,) + tuple(t.shape[1:]))
-                 for r, (lo, hi) in enumerate(bounds)]
-        full.append(torch.cat(parts, dim=0).to(out_dev))
-        off += maxrows * re
+    if per_resample:
+        bounds = [shard_bounds(R, r, n) for r in range(n)]
+        maxrows = max(hi - lo for lo, hi in bounds)
+        row_elems = [int(np.prod(t.shape[1:])) for t in per_resample]
+        send = torch.zeros(maxrows * sum(row_elems), dtype=torch.float64, device=dev)
+        off = 0
+        for t, re in zip(per_resample, row_elems):
+            send[off:off + t.numel()] = t.reshape(-1).to(dev)
+            off += maxrows * re
+        recv = [torch.empty_like(send) for _ in range(n)]
+        td.all_gather(recv, send)
+        off = 0
+        for t, re in zip(per_resample, row_elems):
+            parts = [recv[r][off:off + (hi - lo) * re].reshape((hi - lo,) + tuple(t.shape[1:]))
+                     for r, (lo, hi) in enumerate(bounds)]
+            full.append(torch.cat(parts, dim=0).to(out_dev))
+            off += maxrows * re
     sums = []
-    for t, se in zip(summed, sum_elems):
-        acc = recv[0][off:off + se].clone()
-        for r in range(1, n):
-            acc += recv[r][off:off + se]
-        sums.append(acc.reshape(t.shape).to(out_dev))
-        off += se
+    if summed:
+        flat = torch.cat([t.reshape(-1).to(dev) for t in summed])
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        off = 0
+        for t in summed:
+            sums.append(flat[off:off + t.numel()].reshape(t.shape).to(out_dev))
+            off += t.numel()
     return full, sums
