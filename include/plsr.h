@@ -244,6 +244,17 @@ int plsr_rng_task_permutations(uint32_t *key, int32_t *pos, const int32_t *table
 int plsr_rng_bootstraps(uint32_t *key, int32_t *pos, const int32_t *table,
                         const int32_t *group_subjects, int32_t ngroups, int32_t nc, int32_t count,
                         int32_t *out);
+/* `count` tries of the multiblock permutation (bootstrap_permutation.py:343-347): per try a
+ * task permutation, then np.random.permutation(nrows) for the behaviour block */
+int plsr_rng_mb_permutations(uint32_t *key, int32_t *pos, const int32_t *table, int32_t nsub,
+                             int32_t nc, int32_t nrows, int32_t count, int32_t *out_task,
+                             int32_t *out_rows);
+/* `count` tries of the multiblock bootstrap (:547-553): per try a task bootstrap on `table`
+ * (nc conditions), then a behaviour bootstrap on `btable` (bnc conditions, same groups) */
+int plsr_rng_mb_bootstraps(uint32_t *key, int32_t *pos, const int32_t *table,
+                           const int32_t *group_subjects, int32_t ngroups, int32_t nc,
+                           const int32_t *btable, int32_t bnc, int32_t count, int32_t *out_task,
+                           int32_t *out_beh);
 
 /*
  * Optional overlap of the reduction tail.  plsr_boot_batch ends with HBM-bound

@@ -54,6 +54,8 @@ SIGNATURES = {
     "plsr_rng_permutation": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "plsr_rng_task_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "plsr_rng_bootstraps": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "plsr_rng_mb_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "plsr_rng_mb_bootstraps": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "plsr_set_tail_stream": (c_i32, [c_vp]),
     "plsr_timing_enable": (c_i32, [c_i32]),
     "plsr_timing_collect": (c_i32, [c_vp, c_vp, c_i32]),

@@ -228,19 +228,18 @@ class _ResampleTestPLS(ResampleTest):
         group std of the permuted Y is 0 (:333-355; the guard uses the full
         cond_order even on the bscan subset, quirk Q8)."""
         co = self._cond_order
-        rows = np.empty((niter, Ysrc.shape[0]), dtype=np.int32)
-        task = np.empty((niter, int(co.sum())), dtype=np.int32) if with_task else None
-        table = np.concatenate(resample.subject_tables(co)) if with_task else None
-        for i in range(niter):
-            for _ in range(100):
-                if with_task:
-                    task[i] = resample.draw_task_permutation(table)           # :343
-                rows[i] = np.random.permutation(Ysrc.shape[0])                # :338 / :347
-                if not (cf.group_stds(Ysrc[rows[i]], co) == 0).any():
-                    break
-            else:
-                raise Exception(_DEGENERATE)                                   # :355
-        return (np.concatenate((task, rows), axis=1) if with_task else rows)
+        nrows = Ysrc.shape[0]
+        if with_task:
+            got = resample.draw_guarded(
+                niter, lambda m: resample.mb_permutation_tries(co, nrows, m),         # :343, :347
+                lambda task, rows: cf.any_group_std_zero(Ysrc[rows], co))
+        else:
+            got = resample.draw_guarded(
+                niter, lambda m: (resample.permutations(nrows, m),),                  # :338
+                lambda rows: cf.any_group_std_zero(Ysrc[rows], co))
+        if got is None:
+            raise Exception(_DEGENERATE)                                               # :355
+        return np.concatenate(got, axis=1) if with_task else got[0]
 
     def _perm_rb(self, U, s, niter, threshold=1e-12):
         """:266-464 for rb.  Only Y is permuted; X enters through its per-cell
@@ -405,28 +404,17 @@ class _ResampleTestPLS(ResampleTest):
         resampled Y is 0 (guard on the full cond_order, quirk Q8).  rb: one draw
         per try; mb: task draw then bscan draw per try (:547-553, quirk Q7)."""
         co = self._cond_order
-        tables = resample.subject_tables(co)
-        n = int(co.sum())
-        if not multiblock:
-            out = np.empty((niter, n), dtype=np.int32)
+        if multiblock:
+            got = resample.draw_guarded(
+                niter, lambda m: resample.mb_bootstrap_tries(co, self._bscan, m),     # :547, :551
+                lambda ti, bi: cf.any_group_std_zero(Ysrc[bi], co))                    # :563-564
         else:
-            btables = resample.subject_tables(co[:, list(self._bscan)])
-            out = np.empty((niter, n + Ysrc.shape[0]), dtype=np.int32)
-        for i in range(niter):
-            for _ in range(100):
-                if multiblock:
-                    ti = resample.draw_bootstrap(tables)                       # :547
-                    bi = resample.draw_bootstrap(btables)                      # :551
-                    row = np.concatenate((ti, bi))
-                else:
-                    bi = resample.draw_bootstrap(tables)                       # :557
-                    row = bi
-                if not (cf.group_stds(Ysrc[bi], co) == 0).any():               # :563-564
-                    break
-            else:
-                raise Exception(_DEGENERATE)                                   # :572
-            out[i] = row
-        return out
+            got = resample.draw_guarded(
+                niter, lambda m: (resample.bootstraps(co, m),),                       # :557
+                lambda bi: cf.any_group_std_zero(Ysrc[bi], co))
+        if got is None:
+            raise Exception(_DEGENERATE)                                               # :572
+        return np.concatenate(got, axis=1) if multiblock else got[0]
 
     def _finish_items(self, res, niter, ref):
         """Exchange a sharded boot_items result and form std_errs / boot_ratios."""

@@ -33,6 +33,25 @@ def group_stds(M, cond_order):
     return out
 
 
+def any_group_std_zero(Mb, cond_order):
+    """Batched form of ``(group_stds(M, cond_order) == 0).any()`` for a stack
+    Mb (m, rows, b): True where some column is constant within some group's
+    rows (the degenerate-behaviour guard, bootstrap_permutation.py:349, :563).
+    Same tolerant slicing as group_stds: groups beyond the rows of M are empty
+    (std = nan, never == 0)."""
+    cond_order = np.asarray(cond_order)
+    bad = np.zeros(Mb.shape[0], dtype=bool)
+    start = 0
+    for tot in cond_order.sum(axis=1):
+        blk = Mb[:, start:start + int(tot)]
+        start += int(tot)
+        if blk.shape[1] == 0:
+            continue
+        # np.std == 0 exactly when every deviation from the mean is exactly 0
+        bad |= (np.std(blk, axis=1) == 0).any(axis=-1)
+    return bad
+
+
 def zscore_cells(M, bounds):
     """Per-cell z-score (ddof 0) divided by sqrt(n_cell), constant columns -> 0:
     what class_functions.py:221-238 does to X and to Y (scipy.stats.zscore's

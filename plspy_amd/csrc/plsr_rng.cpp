@@ -18,6 +18,7 @@
 // advanced, and puts them into np.random.set_state(), so the global stream
 // continues exactly as if NumPy had made the draws.  Host index generation was
 // 5x the GPU time of a phase; this removes the Python loop.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -143,6 +144,76 @@ extern "C" int plsr_rng_bootstraps(uint32_t *key, int32_t *pos, const int32_t *t
         for (int s = 0; s < ns; ++s) *o++ = table[(sub0 + pick[s]) * nc + c];
       sub0 += ns;
     }
+  }
+  *pos = mt.pos;
+  return PLSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// multiblock candidates: two draws per try, interleaved on the one stream
+// ---------------------------------------------------------------------------
+namespace {
+void one_task_permutation(MT &mt, const int32_t *table, int nsub, int nc, std::vector<int32_t> &within,
+                          std::vector<int32_t> &colbuf, int32_t *o) {
+  std::memcpy(within.data(), table, sizeof(int32_t) * (size_t)nsub * nc);
+  for (int s = 0; s < nsub; ++s) mt.shuffle(within.data() + (size_t)s * nc, nc);
+  for (int c = 0; c < nc; ++c) {
+    for (int s = 0; s < nsub; ++s) colbuf[s] = within[(size_t)s * nc + c];
+    mt.shuffle(colbuf.data(), nsub);
+    std::memcpy(o + (size_t)c * nsub, colbuf.data(), sizeof(int32_t) * nsub);
+  }
+}
+
+void one_bootstrap(MT &mt, const int32_t *table, const int32_t *group_subjects, int ngroups, int nc,
+                   std::vector<int32_t> &pick, int32_t *o) {
+  int64_t sub0 = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const int ns = group_subjects[g];
+    for (int s = 0; s < ns; ++s) pick[s] = (int32_t)mt.interval((uint32_t)(ns - 1));
+    for (int c = 0; c < nc; ++c)
+      for (int s = 0; s < ns; ++s) *o++ = table[(sub0 + pick[s]) * nc + c];
+    sub0 += ns;
+  }
+}
+}  // namespace
+
+extern "C" int plsr_rng_mb_permutations(uint32_t *key, int32_t *pos, const int32_t *table, int32_t nsub,
+                                        int32_t nc, int32_t nrows, int32_t count, int32_t *out_task,
+                                        int32_t *out_rows) {
+  if (!key || !pos || !table || !out_task || !out_rows || nsub <= 0 || nc <= 0 || nrows <= 0 || count < 0 ||
+      *pos < 0 || *pos > N)
+    return PLSR_EINVAL;
+  MT mt{key, *pos};
+  std::vector<int32_t> within((size_t)nsub * nc), colbuf(nsub);
+  for (int r = 0; r < count; ++r) {
+    one_task_permutation(mt, table, nsub, nc, within, colbuf, out_task + (int64_t)r * nsub * nc);   // :343
+    int32_t *x = out_rows + (int64_t)r * nrows;                                                      // :347
+    for (int i = 0; i < nrows; ++i) x[i] = i;
+    mt.shuffle(x, nrows);
+  }
+  *pos = mt.pos;
+  return PLSR_OK;
+}
+
+extern "C" int plsr_rng_mb_bootstraps(uint32_t *key, int32_t *pos, const int32_t *table,
+                                      const int32_t *group_subjects, int32_t ngroups, int32_t nc,
+                                      const int32_t *btable, int32_t bnc, int32_t count, int32_t *out_task,
+                                      int32_t *out_beh) {
+  if (!key || !pos || !table || !btable || !group_subjects || !out_task || !out_beh || ngroups <= 0 ||
+      nc <= 0 || bnc <= 0 || count < 0 || *pos < 0 || *pos > N)
+    return PLSR_EINVAL;
+  MT mt{key, *pos};
+  int64_t nsub = 0;
+  int maxg = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    if (group_subjects[g] <= 0) return PLSR_EINVAL;
+    nsub += group_subjects[g];
+    maxg = std::max(maxg, (int)group_subjects[g]);
+  }
+  std::vector<int32_t> pick(maxg);
+  for (int r = 0; r < count; ++r) {
+    one_bootstrap(mt, table, group_subjects, ngroups, nc, pick, out_task + (int64_t)r * nsub * nc);   // :547
+    one_bootstrap(mt, btable, group_subjects, ngroups, bnc, pick, out_beh + (int64_t)r * nsub * bnc); // :551
   }
   *pos = mt.pos;
   return PLSR_OK;

@@ -146,3 +146,85 @@ def bootstraps(cond_order, count, native=None):
         for i in range(count):
             out[i] = draw_bootstrap(tables)
     return out
+
+
+def mb_permutation_tries(cond_order, nrows, count, native=None):
+    """``count`` tries of the multiblock permutation (bootstrap_permutation.py:343-347):
+    per try a task permutation, then np.random.permutation(nrows).
+    Returns (task (count, n), rows (count, nrows))."""
+    table = np.ascontiguousarray(np.concatenate(subject_tables(cond_order)), dtype=np.int32)
+    task = np.empty((count, table.size), dtype=np.int32)
+    rows = np.empty((count, nrows), dtype=np.int32)
+    if count == 0:
+        return task, rows
+    if NATIVE if native is None else native:
+        lib, L = _lib()
+        with _GlobalStream() as gs:
+            L.check(lib.plsr_rng_mb_permutations(*gs.args(), table.ctypes.data_as(ctypes.c_void_p),
+                                                 table.shape[0], table.shape[1], nrows, count,
+                                                 task.ctypes.data_as(ctypes.c_void_p),
+                                                 rows.ctypes.data_as(ctypes.c_void_p)),
+                    "plsr_rng_mb_permutations")
+    else:
+        for i in range(count):
+            task[i] = draw_task_permutation(table)
+            rows[i] = np.random.permutation(nrows)
+    return task, rows
+
+
+def mb_bootstrap_tries(cond_order, bscan, count, native=None):
+    """``count`` tries of the multiblock bootstrap (bootstrap_permutation.py:547-553):
+    per try a task bootstrap, then a behaviour bootstrap on the bscan conditions.
+    Returns (task (count, n), beh (count, n_bscan))."""
+    co = np.asarray(cond_order)
+    tables = subject_tables(co)
+    btables = subject_tables(co[:, list(bscan)])
+    n, nb = sum(t.size for t in tables), sum(t.size for t in btables)
+    task = np.empty((count, n), dtype=np.int32)
+    beh = np.empty((count, nb), dtype=np.int32)
+    if count == 0:
+        return task, beh
+    ncs = {t.shape[1] for t in tables}
+    if (NATIVE if native is None else native) and len(ncs) == 1:
+        lib, L = _lib()
+        table = np.ascontiguousarray(np.concatenate(tables), dtype=np.int32)
+        btable = np.ascontiguousarray(np.concatenate(btables), dtype=np.int32)
+        groups = np.array([t.shape[0] for t in tables], dtype=np.int32)
+        with _GlobalStream() as gs:
+            L.check(lib.plsr_rng_mb_bootstraps(*gs.args(), table.ctypes.data_as(ctypes.c_void_p),
+                                               groups.ctypes.data_as(ctypes.c_void_p), len(groups),
+                                               table.shape[1], btable.ctypes.data_as(ctypes.c_void_p),
+                                               btable.shape[1], count, task.ctypes.data_as(ctypes.c_void_p),
+                                               beh.ctypes.data_as(ctypes.c_void_p)),
+                    "plsr_rng_mb_bootstraps")
+    else:
+        for i in range(count):
+            task[i] = draw_bootstrap(tables)
+            beh[i] = draw_bootstrap(btables)
+    return task, beh
+
+
+def draw_guarded(niter, draw_tries, is_bad, max_tries=100):
+    """``niter`` accepted tries from a sequential candidate stream, as the
+    reference's ``for attempt in range(100): draw; if ok: break`` loops do
+    (bootstrap_permutation.py:333-355, :542-572), in batches: a batch draws
+    exactly as many candidates as are still missing, so the RNG stream is
+    consumed exactly as by the one-at-a-time loop.  draw_tries(m) -> tuple of
+    (m, .) arrays; is_bad(*arrays) -> (m,) bool.  Returns the tuple of accepted
+    arrays, or None after ``max_tries`` consecutive bad candidates."""
+    kept = None
+    have, run = 0, 0
+    while have < niter:
+        tries = draw_tries(niter - have)
+        bad = np.asarray(is_bad(*tries), dtype=bool)
+        for b in bad:                                  # consecutive failures across batches
+            run = run + 1 if b else 0
+            if run >= max_tries:
+                return None
+        good = np.flatnonzero(~bad)
+        if kept is None:
+            kept = [np.empty((niter,) + t.shape[1:], dtype=t.dtype) for t in tries]
+        for k, t in zip(kept, tries):
+            k[have:have + len(good)] = t[good]
+        have += len(good)
+    return tuple(kept)

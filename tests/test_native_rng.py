@@ -78,3 +78,59 @@ def test_native_is_default_and_fast():
     resample.bootstraps(co, 1000, native=False)
     t_numpy = time.perf_counter() - t0
     assert t_native < t_numpy / 3, (t_native, t_numpy)
+
+
+def test_multiblock_tries_match_the_python_loops():
+    """plsr_rng_mb_permutations / plsr_rng_mb_bootstraps: two draws per try,
+    interleaved on np.random's stream, bit-exact against the Python loops."""
+    from plspy_amd import resample
+    co = np.array([[5, 5, 5], [4, 4, 4]])
+    for seed in (0, 7):
+        np.random.seed(seed)
+        a_t, a_r = resample.mb_permutation_tries(co, 18, 9, native=False)
+        tail_a = np.random.randint(0, 1 << 30, size=3)
+        np.random.seed(seed)
+        b_t, b_r = resample.mb_permutation_tries(co, 18, 9, native=True)
+        tail_b = np.random.randint(0, 1 << 30, size=3)
+        np.testing.assert_array_equal(a_t, b_t)
+        np.testing.assert_array_equal(a_r, b_r)
+        np.testing.assert_array_equal(tail_a, tail_b)          # stream left in the same state
+        np.random.seed(seed)
+        a_t, a_b = resample.mb_bootstrap_tries(co, [0, 2], 11, native=False)
+        tail_a = np.random.randint(0, 1 << 30, size=3)
+        np.random.seed(seed)
+        b_t, b_b = resample.mb_bootstrap_tries(co, [0, 2], 11, native=True)
+        tail_b = np.random.randint(0, 1 << 30, size=3)
+        np.testing.assert_array_equal(a_t, b_t)
+        np.testing.assert_array_equal(a_b, b_b)
+        np.testing.assert_array_equal(tail_a, tail_b)
+
+
+def test_guarded_batches_consume_the_stream_like_the_loop():
+    """draw_guarded: candidates are consumed in order, bad ones skipped, no
+    over-draw -- identical results and identical stream state to the reference's
+    one-at-a-time redraw loop, including when many candidates are rejected."""
+    from plspy_amd import resample
+
+    def bad(rows):                       # rejects about 40 % of the candidates
+        return (rows[:, 0] % 5) < 2
+
+    for seed in (1, 2, 3):
+        np.random.seed(seed)
+        want = np.empty((40, 12), dtype=np.int32)
+        for i in range(40):
+            while True:
+                r = np.random.permutation(12)
+                if not bad(r[None])[0]:
+                    break
+            want[i] = r
+        tail_a = np.random.randint(0, 1 << 30, size=3)
+        np.random.seed(seed)
+        (got,) = resample.draw_guarded(40, lambda m: (resample.permutations(12, m),), bad)
+        tail_b = np.random.randint(0, 1 << 30, size=3)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(tail_a, tail_b)
+    # 100 consecutive rejections -> None (the caller raises the reference's exception)
+    np.random.seed(0)
+    assert resample.draw_guarded(3, lambda m: (resample.permutations(4, m),),
+                                 lambda rows: np.ones(len(rows), dtype=bool)) is None
