@@ -260,7 +260,7 @@ class _ResampleTestPLS(ResampleTest):
         Yz = cf.zscore_cells(Y[perms], bounds)                                 # R x n x b
         cols = np.empty((niter, k, n))
         for c, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
-            cols[:, :, lo:hi] = np.einsum("rib,bj->rji", Yz[:, lo:hi], U[c * b:(c + 1) * b])
+            cols[:, :, lo:hi] = np.swapaxes(Yz[:, lo:hi] @ U[c * b:(c + 1) * b], 1, 2)     # (r,i,b)(b,j) -> r,j,i
         s_hat = np.sqrt(self._run_perm(eng_z, k, niter, cols=cols))
         if self._C is None:
             s_hat[np.abs(s_hat) < threshold] = 0
@@ -323,7 +323,7 @@ class _ResampleTestPLS(ResampleTest):
         total_hat = rownorm2.sum(axis=1)                                         # :419
         with np.errstate(divide="ignore", invalid="ignore"):
             scaledU = U[None] / np.sqrt(rownorm2)[:, :, None]                    # D^-1 U per resample
-        cols = np.einsum("rki,rkj->rji", A, scaledU)
+        cols = np.swapaxes(scaledU, 1, 2) @ A                         # (r,j,k)(r,k,i) -> r,j,i
         s_hat = np.sqrt(self._run_perm(eng_c, q, niter, cols=cols))              # :404-405 / :431-432
         if self._C is None:
             per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)      # quirk Q3 (:421-423)
@@ -386,7 +386,7 @@ class _ResampleTestPLS(ResampleTest):
 
         # left_sv_sampled[i] = permuted_i @ V = W P_i (X V)   (:617, :631) -- p-free
         XV = np.asarray(self._X, dtype=float) @ V
-        left = np.einsum("cr,brk->bck", self._W, XV[inds])
+        left = self._W @ XV[inds]                                     # (c,r)(b,r,k) -> b,c,k
         debug = {
             "left_sv_sampled": left,
             "right_sv_sampled": per[2].cpu().numpy() if keep_right_sv else None,
@@ -449,7 +449,7 @@ class _ResampleTestPLS(ResampleTest):
             Yz = cf.zscore_cells(Y[mine[a:z]], bounds)
             ops = np.empty((z - a, k, n))
             for c, (l, h) in enumerate(zip(bounds[:-1], bounds[1:])):
-                ops[:, :, l:h] = np.einsum("rib,bj->rji", Yz[:, l:h], U[c * b:(c + 1) * b])
+                ops[:, :, l:h] = np.swapaxes(Yz[:, l:h] @ U[c * b:(c + 1) * b], 1, 2)
             return ops
 
         res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref)
@@ -512,7 +512,7 @@ class _ResampleTestPLS(ResampleTest):
             A = raw_rows(a, z)
             with np.errstate(divide="ignore", invalid="ignore"):
                 scaled = U[None] / rownorm[:, :, None]
-            return np.einsum("rkj,rki->rji", scaled, A)
+            return np.swapaxes(scaled, 1, 2) @ A                      # (r,j,k)(r,k,i) -> r,j,i
 
         res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n)
         std_errs, boot_ratios, Zn = self._finish_items(res, niter, ref)

@@ -165,7 +165,7 @@ def corr_rows(L, Yz, bounds):
     """Stacked per-cell Yz.T @ zscore(L) for batches: L (R, n, k), Yz (R, n, b)
     already z-scored -> (R, cells*b, k)  (class_functions.py:185-247 on latents)."""
     Lz = zscore_cells(L, bounds)
-    return np.concatenate([np.einsum("rib,rik->rbk", Yz[:, lo:hi], Lz[:, lo:hi])
+    return np.concatenate([np.swapaxes(Yz[:, lo:hi], 1, 2) @ Lz[:, lo:hi]
                            for lo, hi in zip(bounds[:-1], bounds[1:])], axis=1)
 
 
