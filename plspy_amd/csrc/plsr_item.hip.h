@@ -151,93 +151,129 @@ struct LatentArgs {
 constexpr int LV_T = 32;      // voxels per staged tile
 constexpr int LV_LD = 34;     // padded LDS row (conflict-free row-strided ds_read_b64)
 
-// MC = 16-row tiles of latent variables; NI = 16-row tiles of data rows per wave
-template <int MC, int NI>
-__global__ __launch_bounds__(256, 2) void latent_kernel(LatentArgs A) {
+// MC = 16-row tiles of latent variables; NI = 16-row tiles of data rows per wave;
+// IG = items per workgroup: they share every staged X tile (X is re-read once
+// per IG items instead of once per item) and the two barriers per tile;
+// WV = waves per workgroup (each owns NI tiles of data rows).
+// The global loads of tile t+1 are issued before the MFMAs of tile t and parked
+// in registers, so only the LDS write sits between the two barriers.
+template <int MC, int NI, int IG, int WV>
+__global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15;
   const int g = lane >> 4;
-  const int item = blockIdx.x;
+  const int item0 = blockIdx.x * IG;
   const int chunk = blockIdx.y;
-  constexpr int nrow_x = WAVES * NI * 16;         // every wave's NI tiles of data rows (zero padded)
-  double *Vs = smem;                              // [MC*16][LV_LD]   VS^T tile
-  double *Xs = smem + (size_t)MC * 16 * LV_LD;    // [nrow_x][LV_LD]  X tile
+  constexpr int nrow_x = WV * NI * 16;            // every wave's NI tiles of data rows (zero padded)
+  constexpr int RPP = WV * 2;                     // rows staged per pass (32 voxels per row)
+  constexpr int NV = (IG * MC * 16 + RPP - 1) / RPP;   // passes over the VS^T rows
+  constexpr int NX = nrow_x / RPP;                     // passes over the X rows
+  double *Vs = smem;                              // [IG][MC*16][LV_LD]   VS^T tiles
+  double *Xs = smem + (size_t)IG * MC * 16 * LV_LD;    // [nrow_x][LV_LD]  X tile
   const int64_t nvt = (A.p + LV_T - 1) / LV_T;
   const int64_t t_lo = (int64_t)chunk * A.tiles_per_chunk;
   const int64_t t_hi = min(nvt, t_lo + A.tiles_per_chunk);
-  const double *vsi = A.vst + (int64_t)item * A.k * A.ldv;
+  const int srow = tid >> 5, svox = tid & 31;
 
-  f64x4 acc[MC][NI];
-  double nsq[MC];
+  f64x4 acc[IG][MC][NI];
+  double nsq[IG][MC];
 #pragma unroll
-  for (int mc = 0; mc < MC; ++mc) {
-    nsq[mc] = 0.0;
+  for (int ig = 0; ig < IG; ++ig)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mc][ni] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  }
+    for (int mc = 0; mc < MC; ++mc) {
+      nsq[ig][mc] = 0.0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[ig][mc][ni] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
 
+  double pv[NV], px[NX];
+  auto fetch = [&](int64_t vt) {
+    const int64_t vv = vt * LV_T + svox;
+    const bool inv = vv < A.p && vt < t_hi;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int rr = q * RPP + srow;                        // row of the stacked [IG][MC*16] tile
+      const int ig = rr / (MC * 16), row = rr % (MC * 16);
+      const int item = min(item0 + ig, A.items - 1);        // a short last group recomputes the last item
+      pv[q] = (inv && rr < IG * MC * 16 && row < A.k) ? A.vst[((int64_t)item * A.k + row) * A.ldv + vv] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const int row = q * RPP + srow;
+      px[q] = (inv && row < A.n) ? A.X[(int64_t)row * A.ldx + vv] : 0.0;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int rr = q * RPP + srow;
+      if (rr < IG * MC * 16) Vs[rr * LV_LD + svox] = pv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NX; ++q) Xs[(q * RPP + srow) * LV_LD + svox] = px[q];
+  };
+
+  fetch(t_lo);
   for (int64_t vt = t_lo; vt < t_hi; ++vt) {
-    const int64_t v0 = vt * LV_T;
+    __syncthreads();                  // everybody is done reading the previous tile
+    park();
     __syncthreads();
-    // 32 voxels per row: thread (row = tid/32 + 8*pass, voxel = tid%32)
-    for (int r0 = 0; r0 < MC * 16; r0 += 8) {
-      const int row = r0 + (tid >> 5);
-      const int64_t vv = v0 + (tid & 31);
-      Vs[row * LV_LD + (tid & 31)] = (row < A.k && vv < A.p) ? vsi[(int64_t)row * A.ldv + vv] : 0.0;
-    }
-    for (int r0 = 0; r0 < nrow_x; r0 += 8) {
-      const int row = r0 + (tid >> 5);
-      const int64_t vv = v0 + (tid & 31);
-      Xs[row * LV_LD + (tid & 31)] = (row < A.n && vv < A.p) ? A.X[(int64_t)row * A.ldx + vv] : 0.0;
-    }
-    __syncthreads();
+    fetch(vt + 1);                    // in flight during the MFMAs below
 #pragma unroll
     for (int s = 0; s < LV_T / 4; ++s) {
-      double a[MC];
-#pragma unroll
-      for (int mc = 0; mc < MC; ++mc) {
-        a[mc] = Vs[(mc * 16 + col) * LV_LD + 4 * s + g];        // A[m = j][k = v]
-        nsq[mc] = fma(a[mc], a[mc], nsq[mc]);
-      }
+      double b[NI];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int it = wave * NI + ni;                          // this wave's tiles of data rows
-        const double b = Xs[(it * 16 + col) * LV_LD + 4 * s + g];   // B[k = v][n = i]
+        b[ni] = Xs[(it * 16 + col) * LV_LD + 4 * s + g];            // B[k = v][n = i]
+      }
 #pragma unroll
-        for (int mc = 0; mc < MC; ++mc) acc[mc][ni] = mfma_f64(a[mc], b, acc[mc][ni]);
+      for (int ig = 0; ig < IG; ++ig) {
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) {
+          const double a = Vs[((ig * MC + mc) * 16 + col) * LV_LD + 4 * s + g];   // A[m = j][k = v]
+          nsq[ig][mc] = fma(a, a, nsq[ig][mc]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[ig][mc][ni] = mfma_f64(a, b[ni], acc[ig][mc][ni]);
+        }
       }
     }
   }
 
   // Zt[j = 16 mc + g + 4 r][i = 16 (wave*NI + ni) + col]
-  double *zo = A.Zt_part + ((int64_t)chunk * A.items + item) * A.k * A.n;
 #pragma unroll
-  for (int mc = 0; mc < MC; ++mc)
+  for (int ig = 0; ig < IG; ++ig) {
+    const int item = item0 + ig;
+    if (item >= A.items) break;
+    double *zo = A.Zt_part + ((int64_t)chunk * A.items + item) * A.k * A.n;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = mc * 16 + g + 4 * r;
-        const int i = (wave * NI + ni) * 16 + col;
-        if (j < A.k && i < A.n) zo[(int64_t)j * A.n + i] = acc[mc][ni][r];
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = mc * 16 + g + 4 * r;
+          const int i = (wave * NI + ni) * 16 + col;
+          if (j < A.k && i < A.n) zo[(int64_t)j * A.n + i] = acc[ig][mc][ni][r];
+        }
+    if (wave == 0) {
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) {
+        double x = nsq[ig][mc];
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        const int j = mc * 16 + col;
+        if (g == 0 && j < A.k) A.nsq_part[((int64_t)chunk * A.items + item) * A.k + j] = x;
       }
-  if (wave == 0) {
-#pragma unroll
-    for (int mc = 0; mc < MC; ++mc) {
-      double x = nsq[mc];
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);
-      const int j = mc * 16 + col;
-      if (g == 0 && j < A.k) A.nsq_part[((int64_t)chunk * A.items + item) * A.k + j] = x;
     }
   }
 }
 
-inline size_t latent_lds_bytes(int mc, int ni) {
-  return ((size_t)mc * 16 + (size_t)WAVES * ni * 16) * LV_LD * sizeof(double);
+inline size_t latent_lds_bytes(int mc, int ni, int ig, int wv) {
+  return ((size_t)ig * mc * 16 + (size_t)wv * ni * 16) * LV_LD * sizeof(double);
 }
 
 }  // namespace plsr

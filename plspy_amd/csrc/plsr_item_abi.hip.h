@@ -42,19 +42,33 @@ bool item_plan(int32_t n, int32_t k, int32_t items, int64_t p, ItemPlan &pl) {
   return true;
 }
 
+// items per workgroup of the latent kernel: bounded by the accumulator tiles
+// (IG * MC * NI x 8 VGPRs) that fit without scratch
+constexpr int latent_group_cap(int mc, int ni) {
+  const int c = 12 / (mc * ni);
+  return c < 1 ? 1 : (c > 3 ? 3 : c);
+}
+
 struct LatentPlan {
-  int MC, NI, nchunk, tiles_per_chunk;
+  int MC, NI, IG, WV, ngroups, nchunk, tiles_per_chunk;
   size_t lds, z_elems, n_elems, bytes;
 };
 
 bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl) {
   if (n <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
   pl.MC = (k + 15) / 16;
-  pl.NI = ((n + 15) / 16 + WAVES - 1) / WAVES;
-  if (pl.MC > 4 || pl.NI > 4) return false;
-  pl.lds = latent_lds_bytes(pl.MC, pl.NI);
+  // eight waves (one tile of data rows each) when there are that many tiles: small
+  // accumulators, four waves per SIMD at two workgroups per CU
+  pl.WV = (n + 15) / 16 > 4 ? 8 : 4;
+  pl.NI = ((n + 15) / 16 + pl.WV - 1) / pl.WV;
+  if (pl.MC > 4 || pl.NI > 2) return false;
+  // items per workgroup: as many as the accumulators allow (IG * MC * NI tiles of 8 VGPRs)
+  pl.IG = latent_group_cap(pl.MC, pl.NI);
+  pl.IG = std::min(pl.IG, (int)items);
+  pl.ngroups = (items + pl.IG - 1) / pl.IG;
+  pl.lds = latent_lds_bytes(pl.MC, pl.NI, pl.IG, pl.WV);
   const int64_t nvt = (p + LV_T - 1) / LV_T;
-  int want = (int)std::max<int64_t>(1, (1024 + items - 1) / items);
+  int want = (int)std::max<int64_t>(1, (1024 + pl.ngroups - 1) / pl.ngroups);
   want = (int)std::min<int64_t>(want, nvt);
   pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
   pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
@@ -74,14 +88,31 @@ int run_item(const ItemArgs &a, const ItemPlan &pl, hipStream_t st) {
   return launch_ok();
 }
 
-template <int MC, int NI>
-int run_latent(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
-  auto kern = latent_kernel<MC, NI>;
+template <int MC, int NI, int IG, int WV>
+int run_latent_wv(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
+  auto kern = latent_kernel<MC, NI, IG, WV>;
   if (pl.lds > 64 * 1024 &&
       hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
     return PLSR_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.items, (unsigned)pl.nchunk), dim3(256), pl.lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)pl.ngroups, (unsigned)pl.nchunk), dim3(WV * 64), pl.lds, st, a);
   return launch_ok();
+}
+
+template <int MC, int NI, int IG>
+int run_latent_ig(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
+  return pl.WV == 8 ? run_latent_wv<MC, NI, IG, 8>(a, pl, st) : run_latent_wv<MC, NI, IG, 4>(a, pl, st);
+}
+
+template <int MC, int NI>
+int run_latent(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
+  constexpr int cap = latent_group_cap(MC, NI);
+  if constexpr (cap >= 3) {
+    if (pl.IG >= 3) return run_latent_ig<MC, NI, 3>(a, pl, st);
+  }
+  if constexpr (cap >= 2) {
+    if (pl.IG >= 2) return run_latent_ig<MC, NI, 2>(a, pl, st);
+  }
+  return run_latent_ig<MC, NI, 1>(a, pl, st);
 }
 }  // namespace
 
@@ -158,8 +189,7 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
   int rc = PLSR_EUNSUPPORTED;
 #define PLSR_L(M, N) \
   if (pl.MC == M && pl.NI == N) rc = run_latent<M, N>(a, pl, st);
-  PLSR_L(1, 1) PLSR_L(1, 2) PLSR_L(1, 3) PLSR_L(1, 4) PLSR_L(2, 1) PLSR_L(2, 2) PLSR_L(2, 3) PLSR_L(2, 4)
-  PLSR_L(3, 1) PLSR_L(3, 2) PLSR_L(3, 3) PLSR_L(3, 4) PLSR_L(4, 1) PLSR_L(4, 2) PLSR_L(4, 3) PLSR_L(4, 4)
+  PLSR_L(1, 1) PLSR_L(1, 2) PLSR_L(2, 1) PLSR_L(2, 2) PLSR_L(3, 1) PLSR_L(3, 2) PLSR_L(4, 1) PLSR_L(4, 2)
 #undef PLSR_L
   if (rc) return rc;
   const int64_t EZ = (int64_t)items * k * n, EN = (int64_t)items * k;
