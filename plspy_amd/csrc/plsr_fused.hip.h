@@ -183,15 +183,23 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
     const int64_t v = v0 + (e % TVX);
     smem[e] = v < A.p ? A.X[(int64_t)row * A.ldx + v] : 0.0;
   }
-  __syncthreads();
   const char *Xb = (const char *)smem + ((vb * NT) * 16 + col) * 8;   // + rowoff + nt*128
 
   const int per = (A.items + gridDim.y - 1) / gridDim.y;
   const int it_lo = blockIdx.y * per;
   const int it_hi = min(A.items, it_lo + per);
-  if (it_lo >= it_hi) return;
   const int nkp = A.cells.nkp;
   const int ncell = A.cells.ncell;
+  // ---- and the row-offset table of this workgroup's items (a second vector
+  // stream from L2 next to the fragments stalled the vector L1) ----
+  int32_t *tbl = (int32_t *)(smem + (size_t)A.n * TVX);
+  {
+    const int cnt = (max(it_hi - it_lo, 0) * nkp + 8) * 4;        // + 8 steps of look-ahead padding
+    const int32_t *src = A.rowoff + (size_t)it_lo * nkp * 4;      // (the buffer carries the same padding)
+    for (int e = tid; e < cnt; e += blockDim.x) tbl[e] = src[e];
+  }
+  __syncthreads();
+  if (it_lo >= it_hi) return;
 
   // voxel of tile nt = vbase + 16 nt (kept as one register, not NT of them)
   const int64_t vbase = v0 + vb * NT * 16 + col;
@@ -218,17 +226,14 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   // item boundaries.  The k-loops hold no memory operation besides the rings
   // (the scale / shift of a cell are prefetched one cell ahead, between loops).
   const double *fp = A.frag + ((size_t)mc * A.items * nkp + (size_t)it_lo * nkp) * 64 + lane;
-  const int32_t *rp = A.rowoff + ((size_t)it_lo * nkp) * 4 + g;
+  const int32_t *rp = tbl + g;           // LDS: byte offset of the row of (step, lane group)
   double ra[4];
-  int ro[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    ra[u] = fp[(size_t)u * 64];
-    ro[u] = rp[u * 4];
-  }
+  for (int u = 0; u < 4; ++u) ra[u] = fp[(size_t)u * 64];
   double bn[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + ro[0] + nt * 128);
+  for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + rp[0] + nt * 128);
+  int ro1 = rp[4];                       // rows of the next step
 
   // Unconditional loads (clamped addresses): a select on the loaded value would
   // make the prefetch wait for its own data.  Lanes past p read voxel p-1 and
@@ -267,9 +272,9 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
       const double *fq = fp + (size_t)pos * 64;
       const int32_t *rq = rp + pos * 4;
 
-      // one k-step: uses ring slot u, reads the raw rows of the next step
-      // through ring slot un, refills slot u four steps ahead
-      auto step = [&](int sidx, int u, int un) {
+      // one k-step: uses fragment ring slot u (refilled four steps ahead), reads the
+      // raw rows of the next step and the row offsets of the one after (both LDS)
+      auto step = [&](int sidx, int u, int) {
         double z[NT];
 #pragma unroll
 #if PLSR_ABLATE & 512
@@ -277,14 +282,14 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
 #else
         for (int nt = 0; nt < NT; ++nt) z[nt] = fma(bn[nt], sc[nt], sh[nt]);
 #endif
-        const int ron = ro[un];
+        const int ron = ro1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + ron + nt * 128);
+        ro1 = rq[(sidx + 2) * 4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(ra[u], z[nt], acc[nt]);
         ra[u] = fq[(size_t)(sidx + 4) * 64];
-        ro[u] = rq[(sidx + 4) * 4];
       };
 
       // A cell rarely has a multiple of four steps, so the ring slot of its first

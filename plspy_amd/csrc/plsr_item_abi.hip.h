@@ -235,8 +235,8 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   }
   pl.VB = pl.TVX / (16 * pl.NT);
   pl.waves = pl.MC * pl.VB;
-  pl.lds = (size_t)n * pl.TVX * sizeof(double);
-  if (pl.lds > 160 * 1024) return false;
+  const size_t lds_x = (size_t)n * pl.TVX * sizeof(double);
+  if ((size_t)n * TV * sizeof(double) > 160 * 1024) return false;      // the statistics kernel's tile
   pl.cells.ncell = ncell;
   int steps = 0;
   for (int c = 0; c < ncell; ++c) {
@@ -251,6 +251,18 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   pl.cells.nkp = steps;
   pl.nvt = (p + pl.TVX - 1) / pl.TVX;
   pl.nsplit = (int)std::min<int64_t>(items, std::max<int64_t>(1, (1024 + pl.nvt - 1) / pl.nvt));
+  // the row-offset table of a workgroup's items sits in LDS next to the X tile:
+  // split the items further until it fits in 16 KiB (or what the tile leaves)
+  {
+    const size_t room = std::min<size_t>(16 * 1024, 160 * 1024 - std::min<size_t>(lds_x, 160 * 1024));
+    const size_t per_item = (size_t)steps * 16;
+    if (room < per_item + 128) return false;
+    const int64_t fit = (int64_t)((room - 128) / per_item);
+    pl.nsplit = (int)std::max<int64_t>(pl.nsplit, (items + fit - 1) / fit);
+    const int64_t per = (items + pl.nsplit - 1) / pl.nsplit;
+    pl.lds = lds_x + ((size_t)per * steps + 8) * 16;
+  }
+  if (pl.lds > 160 * 1024) return false;
   pl.nslab = pl.nvt * pl.VB;
   pl.nchunk = (int)((pl.nslab + 63) / 64);
   size_t off = 0;
