@@ -226,6 +226,20 @@ int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     size_t work_bytes, void *stream);
 
 /*
+ * plsr_gram_batch with the gather / z-score of K4f fused in (split-half of
+ * behaviour / multiblock PLS, split_half_resampling.py:136-398): item b's matrix
+ * is X[d_src[b]] z-scored within the cells, never stored; G_b = (rows_b Z_b)(rows_b Z_b)^T.
+ *   d_src : [items][nz] int32, cell_lo / cell_z : HOST arrays as in plsr_item_fused,
+ *   d_frag: plsr_ops_pack_rows(items, m, nz)
+ */
+size_t plsr_gram_fused_workspace_bytes(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo,
+                                       int32_t ncell, int32_t items, int64_t p);
+int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src,
+                    int32_t nz, const int32_t *cell_lo, const int32_t *cell_z, int32_t ncell,
+                    const double *d_frag, int32_t items, int32_t m, double *d_G, void *d_work,
+                    size_t work_bytes, void *stream);
+
+/*
  * ---- host: bit-exact NumPy legacy RandomState draws -------------------------
  * (no GPU involved; these run wherever the library loads).  key[624] / *pos are
  * np.random.get_state()[1:3]; they come back advanced so that

@@ -36,11 +36,18 @@ struct GramArgs {
   int32_t tiles_per_chunk;   // 64-voxel tiles per voxel chunk
   int32_t ks;                // k-steps of X staged in LDS at a time (rows of X are K-chunked)
   double *G_part;        // [nchunk][items][mm][mm]
+  // fused gather / z-score (template FUSED): the item's matrix is never stored;
+  // row r of item b is X[src[b][r]] * sc[b][cell(r)] + sh[b][cell(r)]  (plsr_fused.hip.h)
+  const int32_t *src;        // [items][n]
+  const int32_t *rowcell;    // [n] cell of every row
+  int32_t ncell;
+  const double *sc, *sh;     // [items][ncell][p]
 };
 
 // MC = 16-row tiles per item, B = items per workgroup
-template <int MC, int B>
+template <int MC, int B, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
+  static_assert(!FUSED || B == 1, "fused items do not share a tile");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NG = MC * (MC + 1) / 2;
   constexpr int MM = MC * 16;
@@ -88,6 +95,47 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
     for (int ks0 = 0; ks0 < A.nk; ks0 += A.ks) {
       const int ks1 = min(A.nk, ks0 + A.ks);
       __syncthreads();                                  // previous X chunk fully consumed (and ops written)
+      if (FUSED) {
+        // every wave stages a run of consecutive rows: the scale / shift of a cell
+        // are then loaded once per cell and chunk, not once per element
+        const int rows_chunk = 4 * (ks1 - ks0);
+        const int rpw = (rows_chunk + WAVES - 1) / WAVES;
+        const int rbeg = 4 * ks0 + wave * rpw;
+        const int rend = min(4 * ks1, rbeg + rpw);
+        const int64_t v = v0 + lane;
+        const bool vin = v < A.p;
+        const int32_t *srci = A.src + (int64_t)item0 * A.n;
+        int ccur = -1;
+        double scv = 0.0, shv = 0.0;
+        for (int r = rbeg; r < rend; r += 4) {
+          double xv[4];
+          int cc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = r + u;
+            const bool ok = row < rend && row < A.n;
+            cc[u] = ok ? A.rowcell[row] : -1;
+            xv[u] = (ok && vin) ? A.X[(int64_t)srci[ok ? row : 0] * A.ldx + v] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = r + u;
+            if (row < rend) {
+              double val = 0.0;
+              if (cc[u] >= 0) {
+                if (cc[u] != ccur) {
+                  ccur = cc[u];
+                  const int64_t sidx = ((int64_t)item0 * A.ncell + ccur) * A.p + min(v, A.p - 1);
+                  scv = A.sc[sidx];
+                  shv = A.sh[sidx];
+                }
+                val = vin ? fma(xv[u], scv, shv) : 0.0;
+              }
+              Xs[xs_index(row - 4 * ks0, lane)] = val;
+            }
+          }
+        }
+      } else
       for (int r0 = 4 * ks0; r0 < 4 * ks1; r0 += 16) {
         double tmp[4];
 #pragma unroll

@@ -394,3 +394,126 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   }
   return launch_ok();
 }
+
+// ---------------------------------------------------------------------------
+// K2 with the gather / z-score fused in (split-half of rb / mb)
+// ---------------------------------------------------------------------------
+namespace {
+struct GramFusedPlan {
+  GramPlan g;
+  FusedCells cells;
+  size_t o_sc, o_sh, o_cell, bytes;
+};
+
+bool gram_fused_plan(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo, const int32_t *cell_z,
+                     int32_t ncell, int32_t items, int64_t p, GramFusedPlan &pl) {
+  if (n <= 0 || !cell_lo || ncell <= 0 || ncell > FZ_MAXCELL || cell_lo[0] != 0 || cell_lo[ncell] != nz)
+    return false;
+  if ((size_t)n * TV * sizeof(double) > 160 * 1024) return false;        // statistics kernel's X tile
+  if (!gram_plan(nz, m, items, p, true, pl.g)) return false;
+  pl.cells.ncell = ncell;
+  int steps = 0;
+  for (int c = 0; c < ncell; ++c) {
+    if (cell_lo[c + 1] <= cell_lo[c]) return false;
+    pl.cells.row_lo[c] = cell_lo[c];
+    pl.cells.step_lo[c] = steps;
+    pl.cells.z[c] = cell_z ? cell_z[c] : 1;
+    steps += (cell_lo[c + 1] - cell_lo[c] + 3) / 4;
+  }
+  pl.cells.row_lo[ncell] = nz;
+  pl.cells.step_lo[ncell] = steps;
+  pl.cells.nkp = steps;
+  size_t off = pl.g.bytes;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  pl.o_sc = take((size_t)items * ncell * p * sizeof(double));
+  pl.o_sh = take((size_t)items * ncell * p * sizeof(double));
+  pl.o_cell = take((size_t)nz * sizeof(int32_t));
+  pl.bytes = off;
+  return true;
+}
+
+__global__ void rowcell_kernel(FusedCells cells, int nz, int32_t *out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nz) return;
+  int c = 0;
+  while (c + 1 < cells.ncell && r >= cells.row_lo[c + 1]) ++c;
+  out[r] = c;
+}
+}  // namespace
+
+extern "C" size_t plsr_gram_fused_workspace_bytes(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo,
+                                                  int32_t ncell, int32_t items, int64_t p) {
+  GramFusedPlan pl;
+  return gram_fused_plan(n, nz, m, cell_lo, nullptr, ncell, items, p, pl) ? pl.bytes : 0;
+}
+
+extern "C" int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src,
+                               int32_t nz, const int32_t *cell_lo, const int32_t *cell_z, int32_t ncell,
+                               const double *d_frag, int32_t items, int32_t m, double *d_G, void *d_work,
+                               size_t work_bytes, void *stream) {
+  if (!d_X || !d_src || !d_frag || !d_G || !d_work || !cell_lo || !cell_z || ldx < p) return PLSR_EINVAL;
+  GramFusedPlan pl;
+  if (!gram_fused_plan(n, nz, m, cell_lo, cell_z, ncell, items, p, pl)) return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char *w = (char *)d_work;
+
+  StatsArgs sa;
+  sa.X = d_X;
+  sa.ldx = ldx;
+  sa.p = p;
+  sa.n = n;
+  sa.nz = nz;
+  sa.items = items;
+  sa.src = d_src;
+  sa.cells = pl.cells;
+  sa.sc = (double *)(w + pl.o_sc);
+  sa.sh = (double *)(w + pl.o_sh);
+  const size_t lds_stats = (size_t)n * TV * sizeof(double);
+  if (lds_stats > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)item_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_stats) != hipSuccess)
+    return PLSR_ELAUNCH;
+  const int64_t nvt = (p + TV - 1) / TV;
+  const int nsplit = (int)std::min<int64_t>(items, std::max<int64_t>(1, (1024 + nvt - 1) / nvt));
+  hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)nvt, (unsigned)nsplit), dim3(256), lds_stats, st, sa);
+  int32_t *rowcell = (int32_t *)(w + pl.o_cell);
+  hipLaunchKernelGGL(rowcell_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, pl.cells, nz, rowcell);
+
+  const GramPlan &g = pl.g;
+  GramArgs a;
+  a.X = d_X;
+  a.x_item_stride = 0;
+  a.ldx = ldx;
+  a.p = p;
+  a.n = nz;
+  a.nk = (nz + 3) / 4;
+  a.frag = d_frag;
+  a.items = items;
+  a.tiles_per_chunk = g.tiles_per_chunk;
+  a.ks = g.ks;
+  a.G_part = (double *)d_work;
+  a.src = d_src;
+  a.rowcell = rowcell;
+  a.ncell = ncell;
+  a.sc = sa.sc;
+  a.sh = sa.sh;
+  int rc = PLSR_EUNSUPPORTED;
+  switch (g.MC) {
+    case 1: rc = launch_gram<1, 1, true>(a, g, st); break;
+    case 2: rc = launch_gram<2, 1, true>(a, g, st); break;
+    case 3: rc = launch_gram<3, 1, true>(a, g, st); break;
+    case 4: rc = launch_gram<4, 1, true>(a, g, st); break;
+    case 5: rc = launch_gram<5, 1, true>(a, g, st); break;
+    case 6: rc = launch_gram<6, 1, true>(a, g, st); break;
+  }
+  if (rc) return rc;
+  const int64_t E = (int64_t)items * g.MM * g.MM;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
+                     (const double *)d_work, d_G, E, g.nchunk, g.nchunk);
+  return launch_ok();
+}

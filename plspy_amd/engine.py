@@ -206,7 +206,10 @@ class ProjectionEngine:
         G = torch.empty((S, mm, mm), dtype=torch.float64, device=self.device)
         per_item = self.lib.plsr_rows_frag_elems(n, m, 1) * 8 + m * n * 8
         if gather is not None:
-            per_item += n * self.p * 8
+            ncell = len(gather["cell_z"])
+            lo_c = (ctypes.c_int32 * (ncell + 1))(*[int(x) for x in gather["cell_lo"]])
+            z_c = (ctypes.c_int32 * ncell)(*[int(x) for x in gather["cell_z"]])
+            per_item += 2 * ncell * self.p * 8                 # per-(item, cell, voxel) scale and shift
         step = max(1, min(S, self.work_limit // max(per_item, 1)))
         for lo in range(0, S, step):
             hi = min(S, lo + step)
@@ -217,18 +220,24 @@ class ProjectionEngine:
             _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_rows), cnt, m, n, _ptr(frag), _stream()),
                        "plsr_ops_pack_rows")
             if gather is None:
-                Z, zstride = self.X, 0
+                need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p, 0)
+                if need == 0:
+                    raise _lib.PlsrError(f"plsr_gram: unsupported shape n={n} m={m}")
+                work = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.check(self.lib.plsr_gram_batch(_ptr(self.X), 0, self.X.stride(0), self.p, n, _ptr(frag),
+                                                    cnt, m, _ptr(G[lo:hi]), _ptr(work), need, _stream()),
+                           "plsr_gram_batch")
             else:
-                Z = self.gather_zscore(gather["src"][lo:hi], gather["cell_lo"], gather["cell_z"])
-                zstride = Z.stride(0)
-            need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p, zstride)
-            if need == 0:
-                raise _lib.PlsrError(f"plsr_gram: unsupported shape n={n} m={m}")
-            work = torch.empty(need, dtype=torch.uint8, device=self.device)
-            ldz = self.X.stride(0) if gather is None else Z.stride(1)
-            _lib.check(self.lib.plsr_gram_batch(_ptr(Z), zstride, ldz, self.p, n, _ptr(frag),
-                                                cnt, m, _ptr(G[lo:hi]), _ptr(work), need, _stream()),
-                       "plsr_gram_batch")
+                # the item matrices (gathered, per-cell z-scored rows of X) exist only
+                # inside the kernel: statistics pass + Gram with the z-score fused in
+                d_src = self.dev(np.ascontiguousarray(gather["src"][lo:hi]), torch.int32)
+                need = self.lib.plsr_gram_fused_workspace_bytes(self.n, n, m, lo_c, ncell, cnt, self.p)
+                if need == 0:
+                    raise _lib.PlsrError(f"plsr_gram_fused: unsupported shape n={n} m={m} ncell={ncell}")
+                work = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.check(self.lib.plsr_gram_fused(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_src), n,
+                                                    lo_c, z_c, ncell, _ptr(frag), cnt, m, _ptr(G[lo:hi]),
+                                                    _ptr(work), need, _stream()), "plsr_gram_fused")
         return G
 
     def gather_zscore(self, src, cell_lo, cell_z):
