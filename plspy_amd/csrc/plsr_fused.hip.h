@@ -81,24 +81,41 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
       // the cell's source rows, 64 at a time in one vector register (lane r holds
       // row lo + r); v_readlane feeds the LDS address, so the row loop carries no
       // memory latency of its own
-      double mu = 0.0;
+      // (four independent partial sums: four LDS reads in flight per wave)
+      auto at = [&](int mine, int r) { return smem[__builtin_amdgcn_readlane(mine, r) + lane]; };
+      double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
       for (int r0 = lo; r0 < hi; r0 += 64) {
         const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
         const int m = min(64, hi - r0);
-#pragma unroll 8
-        for (int r = 0; r < m; ++r) mu += smem[__builtin_amdgcn_readlane(mine, r) + lane];
+        int r = 0;
+        for (; r + 4 <= m; r += 4) {
+          m0 += at(mine, r);
+          m1 += at(mine, r + 1);
+          m2 += at(mine, r + 2);
+          m3 += at(mine, r + 3);
+        }
+        for (; r < m; ++r) m0 += at(mine, r);
       }
-      mu /= cnt;
-      double var = 0.0;
+      const double mu = ((m0 + m1) + (m2 + m3)) / cnt;
+      double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
       for (int r0 = lo; r0 < hi; r0 += 64) {
         const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
         const int m = min(64, hi - r0);
-#pragma unroll 8
-        for (int r = 0; r < m; ++r) {
-          const double d = smem[__builtin_amdgcn_readlane(mine, r) + lane] - mu;
-          var = fma(d, d, var);
+        int r = 0;
+        for (; r + 4 <= m; r += 4) {
+          const double d0 = at(mine, r) - mu, d1 = at(mine, r + 1) - mu;
+          const double d2 = at(mine, r + 2) - mu, d3 = at(mine, r + 3) - mu;
+          q0 = fma(d0, d0, q0);
+          q1 = fma(d1, d1, q1);
+          q2 = fma(d2, d2, q2);
+          q3 = fma(d3, d3, q3);
+        }
+        for (; r < m; ++r) {
+          const double d = at(mine, r) - mu;
+          q0 = fma(d, d, q0);
         }
       }
+      const double var = (q0 + q1) + (q2 + q3);
       const double sd = sqrt(var / cnt);
       // scipy.stats.zscore's constant-slice rule followed by nan_to_num -> 0
       const bool dead = !(sd > 2.220446049250313e-16 * fabs(mu));
