@@ -172,27 +172,13 @@ int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, const int32_t 
                        void *stream);
 
 /*
- * ---- K4 / K5: bootstrap of behaviour / multiblock PLS ------------------------
- * Every bootstrap sample z-scores its own resampled rows (class_functions.py:
- * 221-238 on X[inds]), so each resample ("item") has its own matrix
- * Z_b (n x p), produced by plsr_gather_zscore, and its own k x n operator
- * (z-scored behaviour columns times the observed U; rows layout, see
- * plsr_ops_pack_rows).
- *
- * plsr_item_project (pass A):  VS_b = op_b Z_b  (k x p)
- *     d_S1[v][j] += sum_b (VS_b[j][v] - ref[v][j]),  d_S2 likewise squared
- *     (bootstrap_permutation.py:620-626, :695 streamed);
- *     d_vst[b][j][v] = VS_b[j][v]   (k x ldv per item; input of pass B)
- * plsr_latent (pass B):  d_Zt[b][j][i] = sum_v VS_b[j][v] X[i][v]   (X @ VS_b,
+ * ---- K5: latent scores of the behaviour / multiblock bootstrap -----------------
+ * plsr_latent:  d_Zt[b][j][i] = sum_v VS_b[j][v] X[i][v]   (X @ VS_b,
  *     bootstrap_permutation.py:638/:647/:655 before the column normalisation)
  *     d_nsq[b][j]   = sum_v VS_b[j][v]^2                       (:623 norms)
+ * from d_vst[b][j][v] = VS_b[j][v] (k x ldv per item, written by plsr_item_fused).
  * k <= 64, n <= 256.
  */
-size_t plsr_item_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p);
-int plsr_item_project(const double *d_Z, int64_t z_item_stride, int64_t ldz, int64_t p, int32_t n,
-                      const double *d_frag, int32_t items, int32_t k, const double *d_ref,
-                      double *d_S1, double *d_S2, double *d_vst, int64_t ldv, void *d_work,
-                      size_t work_bytes, void *stream);
 size_t plsr_latent_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p);
 int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const double *d_vst,
                 int64_t ldv, int32_t items, int32_t k, double *d_Zt, double *d_nsq, void *d_work,
@@ -200,8 +186,11 @@ int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const doub
 
 /*
  * ---- K4f: fused gather / z-score / projection ---------------------------------
- * Same result as plsr_gather_zscore followed by plsr_item_project, without the
- * per-item matrix ever reaching HBM: a workgroup keeps X[:, 64 voxels] in LDS
+ * Every bootstrap sample of behaviour / multiblock PLS z-scores its own
+ * resampled rows (class_functions.py:221-238 on X[inds]), so each resample
+ * ("item") has its own matrix Z_b and its own k x nz operator rows;
+ * VS_b = rows_b Z_b.  Same result as plsr_gather_zscore followed by a dense
+ * product, without the per-item matrix ever reaching HBM: a workgroup keeps X[:, 64 voxels] in LDS
  * for all items, gathers rows through d_src, z-scores them on the fly from
  * per-(item, cell, voxel) statistics (two-pass, computed by a first kernel from
  * the same LDS tile) and multiplies by the item's operator rows.

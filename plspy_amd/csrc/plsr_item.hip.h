@@ -1,25 +1,13 @@
-// K4 / K5: bootstrap of behaviour and multiblock PLS, where every resample has
-// its OWN data matrix (rows of X gathered and z-scored within the resample's
-// cells by K3), so resamples cannot share one X tile as in K1.
+// K5: latent scores of the rb / mb bootstrap (K4f, plsr_fused.hip.h, produces VS^T).
 //
-// K4  item_project_kernel<MC>   (pass A, voxel-major)
-//     VS_b[j, v] = sum_i op_b[j, i] * Z_b[i, v]              (k x p per item)
-//     One workgroup owns 64 voxels for ALL items of the launch, so the
-//     bootstrap moments  S1 += VS - ref,  S2 += (VS - ref)^2  stay in
-//     registers across items (bootstrap_permutation.py:620-626, :695 without
-//     the R x p x k stack).  VS_b^T is also written out ([item][j][v]) for K5.
-//     MFMA: M = 16 latent variables, N = 16 voxels (one block per wave), K = 4
-//     rows; operator fragments and the item's X rows are staged per item in
-//     K-chunks through LDS.
-//
-// K5  latent_kernel<MC>         (pass B, item-major)
+// K5  latent_kernel<MC, NI, IG, WV>   (item-major)
 //     Zt_b[j, i] = sum_v VS_b[j, v] * X[i, v]                (k x n per item)
 //     nsq_b[j]   = sum_v VS_b[j, v]^2
 //     i.e. X @ VS_b (class_functions.py:165-182 as used at
 //     bootstrap_permutation.py:638, :647, :655 before the column
-//     normalisation) and the norms of :623.  One workgroup owns (item, voxel
-//     chunk) and accumulates over its voxels in registers; chunk partials are
-//     summed afterwards in fixed order.
+//     normalisation) and the norms of :623.  One workgroup owns (group of items,
+//     voxel chunk) and accumulates over its voxels in registers; chunk partials
+//     are summed afterwards in fixed order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,115 +16,6 @@
 
 namespace plsr {
 
-struct ItemArgs {
-  const double *Z;        // [items][n][ldz]  per-item matrices
-  int64_t z_item_stride, ldz, p;
-  int32_t n, nk, ks;      // rows, k-steps, k-steps staged per chunk
-  const double *frag;     // [items*MC][nk][64] rows layout (ops_rows_kernel)
-  int32_t items, k;
-  const double *ref;      // [p][k] shift of the moment sums, or null
-  double *S1, *S2;        // [split][p][k] partial sums (overwritten)
-  double *vst;            // [items][k][ldv]  VS^T, or null
-  int64_t ldv;
-};
-
-template <int MC>
-__global__ __launch_bounds__(256, 2) void item_project_kernel(ItemArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 15;
-  const int g = lane >> 4;
-  const int64_t v0 = (int64_t)blockIdx.x * TV;
-  const int64_t v = v0 + wave * 16 + col;                // this lane's voxel
-  double *ops = smem;                                     // [MC][ks][64]
-  double *Xs = smem + (size_t)MC * A.ks * 64;             // [4*ks][64]
-  const int xo = xs_index(g, wave * 16 + col);
-
-  // items are split over blockIdx.y; each split owns its moment partials
-  const int per = (A.items + gridDim.y - 1) / gridDim.y;
-  const int it_lo = blockIdx.y * per;
-  const int it_hi = min(A.items, it_lo + per);
-
-  double s1[MC][4], s2[MC][4], rf[MC][4];
-#pragma unroll
-  for (int mc = 0; mc < MC; ++mc)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = mc * 16 + g + 4 * r;
-      s1[mc][r] = 0.0;
-      s2[mc][r] = 0.0;
-      rf[mc][r] = (A.ref != nullptr && j < A.k && v < A.p) ? A.ref[v * A.k + j] : 0.0;
-    }
-
-  for (int item = it_lo; item < it_hi; ++item) {
-    const double *Zi = A.Z + (int64_t)item * A.z_item_stride;
-    const double *fi = A.frag + (int64_t)item * MC * A.nk * 64;
-    f64x4 D[MC];
-#pragma unroll
-    for (int mc = 0; mc < MC; ++mc) D[mc] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    for (int ks0 = 0; ks0 < A.nk; ks0 += A.ks) {
-      const int ks1 = min(A.nk, ks0 + A.ks);
-      __syncthreads();
-      for (int r0 = 4 * ks0; r0 < 4 * ks1; r0 += 16) {
-        double tmp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = r0 + u * 4 + (tid >> 6);
-          const int64_t vv = v0 + lane;
-          tmp[u] = (row < A.n && vv < A.p) ? Zi[(int64_t)row * A.ldz + vv] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = r0 + u * 4 + (tid >> 6);
-          if (row < 4 * ks1) Xs[xs_index(row - 4 * ks0, lane)] = tmp[u];
-        }
-      }
-      for (int e = tid; e < MC * (ks1 - ks0) * 64; e += 256) {
-        const int mc = e / ((ks1 - ks0) * 64);
-        const int rest = e % ((ks1 - ks0) * 64);
-        ops[((size_t)mc * A.ks) * 64 + rest] = fi[((size_t)mc * A.nk + ks0) * 64 + rest];
-      }
-      __syncthreads();
-      for (int s = 0; s < ks1 - ks0; ++s) {
-        const double b = Xs[(size_t)s * 4 * TV + xo];
-#pragma unroll
-        for (int mc = 0; mc < MC; ++mc) D[mc] = mfma_f64(ops[((size_t)mc * A.ks + s) * 64 + lane], b, D[mc]);
-      }
-    }
-    // D[mc][r] = VS[j = 16 mc + g + 4 r][v]
-#pragma unroll
-    for (int mc = 0; mc < MC; ++mc)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = mc * 16 + g + 4 * r;
-        const double d = D[mc][r] - rf[mc][r];
-        s1[mc][r] += d;
-        s2[mc][r] = fma(d, d, s2[mc][r]);
-        if (A.vst != nullptr && j < A.k && v < A.p) A.vst[((int64_t)item * A.k + j) * A.ldv + v] = D[mc][r];
-      }
-  }
-
-  if (v < A.p) {
-    double *o1 = A.S1 + (int64_t)blockIdx.y * A.p * A.k;
-    double *o2 = A.S2 + (int64_t)blockIdx.y * A.p * A.k;
-#pragma unroll
-    for (int mc = 0; mc < MC; ++mc)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = mc * 16 + g + 4 * r;
-        if (j < A.k) {
-          o1[v * A.k + j] = s1[mc][r];
-          o2[v * A.k + j] = s2[mc][r];
-        }
-      }
-  }
-}
-
-inline size_t item_lds_bytes(int mc, int ks) { return ((size_t)mc * ks * 64 + (size_t)ks * 4 * TV) * sizeof(double); }
-
-// ---------------------------------------------------------------------------
 struct LatentArgs {
   const double *X;        // [n][ldx] raw data (shared by all items)
   int64_t ldx, p;

@@ -1,46 +1,17 @@
-// extern "C" entry points for K4 (item projection) and K5 (latent scores):
-// the bootstrap of behaviour / multiblock PLS.  See include/plsr.h.
+// extern "C" entry points for K4f (fused item projection), the fused Gram and
+// K5 (latent scores): bootstrap and split-half of behaviour / multiblock PLS.
+// See include/plsr.h.
 #include "../../include/plsr.h"
 #include "plsr_item.hip.h"
 #include "plsr_fused.hip.h"
 
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 
 using namespace plsr;
 
 namespace {
 int launch_ok() { return hipGetLastError() == hipSuccess ? PLSR_OK : PLSR_ELAUNCH; }
-
-struct ItemPlan {
-  int MC, ks, nsplit;
-  int64_t nvt;
-  size_t lds, bytes;
-};
-
-bool item_plan(int32_t n, int32_t k, int32_t items, int64_t p, ItemPlan &pl) {
-  if (n <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
-  pl.MC = (k + 15) / 16;
-  if (pl.MC > 4) return false;
-  const int nk = (n + 3) / 4;
-  // keep a workgroup near 52 KiB of LDS so that three fit a CU
-  pl.ks = std::max(1, std::min(nk, (int)(52 * 1024 / (pl.MC * 512 + 2048))));
-  pl.lds = item_lds_bytes(pl.MC, pl.ks);
-  pl.nvt = (p + TV - 1) / TV;
-  pl.nsplit = 1;
-  double best = 0.0;
-  for (int c = 1; c <= 4 && c <= items; ++c) {
-    const double rounds = (double)pl.nvt * c / 768.0;     // 256 CUs x 3 resident workgroups
-    const double eff = rounds / std::ceil(rounds);
-    if (eff > best + 1e-9) {
-      best = eff;
-      pl.nsplit = c;
-    }
-  }
-  pl.bytes = ((size_t)2 * pl.nsplit * p * k * sizeof(double) + 255) / 256 * 256;
-  return true;
-}
 
 // items per workgroup of the latent kernel: bounded by the accumulator tiles
 // (IG * MC * NI x 8 VGPRs) that fit without scratch
@@ -78,16 +49,6 @@ bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl)
   return true;
 }
 
-template <int MC>
-int run_item(const ItemArgs &a, const ItemPlan &pl, hipStream_t st) {
-  auto kern = item_project_kernel<MC>;
-  if (pl.lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
-    return PLSR_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)pl.nvt, (unsigned)pl.nsplit), dim3(256), pl.lds, st, a);
-  return launch_ok();
-}
-
 template <int MC, int NI, int IG, int WV>
 int run_latent_wv(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
   auto kern = latent_kernel<MC, NI, IG, WV>;
@@ -115,51 +76,6 @@ int run_latent(const LatentArgs &a, const LatentPlan &pl, hipStream_t st) {
   return run_latent_ig<MC, NI, 1>(a, pl, st);
 }
 }  // namespace
-
-extern "C" size_t plsr_item_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p) {
-  ItemPlan pl;
-  return item_plan(n, k, items, p, pl) ? pl.bytes : 0;
-}
-
-extern "C" int plsr_item_project(const double *d_Z, int64_t z_item_stride, int64_t ldz, int64_t p,
-                                 int32_t n, const double *d_frag, int32_t items, int32_t k,
-                                 const double *d_ref, double *d_S1, double *d_S2, double *d_vst,
-                                 int64_t ldv, void *d_work, size_t work_bytes, void *stream) {
-  if (!d_Z || !d_frag || !d_S1 || !d_S2 || !d_work || ldz < p || (d_vst && ldv < p)) return PLSR_EINVAL;
-  ItemPlan pl;
-  if (!item_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
-  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
-  ItemArgs a;
-  a.Z = d_Z;
-  a.z_item_stride = z_item_stride;
-  a.ldz = ldz;
-  a.p = p;
-  a.n = n;
-  a.nk = (n + 3) / 4;
-  a.ks = pl.ks;
-  a.frag = d_frag;
-  a.items = items;
-  a.k = k;
-  a.ref = d_ref;
-  a.S1 = (double *)d_work;
-  a.S2 = a.S1 + (size_t)pl.nsplit * p * k;
-  a.vst = d_vst;
-  a.ldv = ldv;
-  hipStream_t st = (hipStream_t)stream;
-  int rc = PLSR_EUNSUPPORTED;
-  switch (pl.MC) {
-    case 1: rc = run_item<1>(a, pl, st); break;
-    case 2: rc = run_item<2>(a, pl, st); break;
-    case 3: rc = run_item<3>(a, pl, st); break;
-    case 4: rc = run_item<4>(a, pl, st); break;
-  }
-  if (rc) return rc;
-  const int64_t cnt = p * k;
-  dim3 g((unsigned)((cnt + 255) / 256));
-  hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S1, (const double *)a.S1, cnt, pl.nsplit);
-  hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S2, (const double *)a.S2, cnt, pl.nsplit);
-  return launch_ok();
-}
 
 extern "C" size_t plsr_latent_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p) {
   LatentPlan pl;
@@ -227,12 +143,6 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   // vector L1 stalls on twice the fragment traffic.)
   pl.TVX = 64;
   pl.NT = pl.MC >= 3 ? 4 : pl.MC;
-  if (const char *e = getenv("PLSR_FUSED_NARROW")) {   // developer switch: 32-voxel workgroups, NT = 2
-    if (e[0] == '1' && pl.MC >= 3) {
-      pl.TVX = 32;
-      pl.NT = 2;
-    }
-  }
   pl.VB = pl.TVX / (16 * pl.NT);
   pl.waves = pl.MC * pl.VB;
   const size_t lds_x = (size_t)n * pl.TVX * sizeof(double);
@@ -373,7 +283,6 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   a.ldv = ldv;
   a.rowsq_part = d_rowsq ? (double *)(w + pl.o_sq) : nullptr;
   int rc = PLSR_EUNSUPPORTED;
-  if (pl.TVX == 32 && pl.NT == 2) rc = run_fused<2, 32>(a, pl, st);
   if (pl.TVX == 64 && pl.NT == 1) rc = run_fused<1, 64>(a, pl, st);
   if (pl.TVX == 64 && pl.NT == 2) rc = run_fused<2, 64>(a, pl, st);
   if (pl.TVX == 64 && pl.NT == 4) rc = run_fused<4, 64>(a, pl, st);

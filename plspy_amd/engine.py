@@ -261,24 +261,6 @@ class ProjectionEngine:
         return out
 
     # -- K4 / K5: bootstrap with per-resample matrices --------------------------
-    def _gram_of_items(self, Z, rows):
-        """Grams (rows_b Z_b)(rows_b Z_b)^T for pre-gathered item matrices Z
-        (cnt, n', p) and operator rows (cnt, m, n')."""
-        cnt, m, n = rows.shape
-        mm = (m + 15) // 16 * 16
-        G = torch.empty((cnt, mm, mm), dtype=torch.float64, device=self.device)
-        d_rows = self.dev(rows)
-        frag = torch.empty(self.lib.plsr_rows_frag_elems(n, m, cnt), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.plsr_ops_pack_rows(_ptr(d_rows), cnt, m, n, _ptr(frag), _stream()),
-                   "plsr_ops_pack_rows")
-        need = self.lib.plsr_gram_workspace_bytes(n, m, cnt, self.p, Z.stride(0))
-        if need == 0:
-            raise _lib.PlsrError(f"plsr_gram: unsupported shape n={n} m={m}")
-        work = torch.empty(need, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.plsr_gram_batch(_ptr(Z), Z.stride(0), Z.stride(1), self.p, n, _ptr(frag), cnt, m,
-                                            _ptr(G), _ptr(work), need, _stream()), "plsr_gram_batch")
-        return G
-
     def item_fused(self, src, cell_lo, cell_z, rows, ref=None, S1=None, S2=None, want_vst=False,
                    want_rowsq=False):
         """K4f: VS_b = rows_b @ Z_b for every item without materialising Z_b
