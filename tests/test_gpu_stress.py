@@ -1,0 +1,145 @@
+"""Randomised shape sweep of the kernels behind the C ABI against direct NumPy
+statements (seeded; a few dozen small problems per kernel).  Complements the
+golden-vector tests: odd voxel counts, one-row cells, k not a multiple of 16,
+item counts that do not fill a workgroup's item group, n on both sides of the
+4-wave / 8-wave switch of the latent kernel."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cells(rs, nz, ncell):
+    cuts = np.sort(rs.choice(np.arange(1, nz), size=ncell - 1, replace=False)) if ncell > 1 else np.array([], int)
+    return np.concatenate(([0], cuts, [nz])).astype(np.int64)
+
+
+def _zscore_items(X, src, cell_lo, zflags):
+    Z = np.empty((src.shape[0], src.shape[1], X.shape[1]))
+    for b in range(src.shape[0]):
+        G = X[src[b]]
+        for c, (lo, hi) in enumerate(zip(cell_lo[:-1], cell_lo[1:])):
+            if zflags[c]:
+                blk = G[lo:hi]
+                mu, sd = blk.mean(0), blk.std(0)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    z = (blk - mu) / sd / np.sqrt(hi - lo)
+                z[:, sd <= 2.220446049250313e-16 * np.abs(mu)] = 0.0
+                Z[b, lo:hi] = z
+            else:
+                Z[b, lo:hi] = G[lo:hi]
+    return Z
+
+
+def test_fused_items_random_shapes():
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(11)
+    for trial in range(24):
+        n = int(rs.randint(5, 140))
+        p = int(rs.choice([1, 15, 64, 65, 129, 300]))
+        nz = int(rs.randint(4, 150))
+        ncell = int(rs.randint(1, min(nz, 9)))
+        k = int(rs.choice([1, 5, 16, 17, 33, 48, 70]))
+        items = int(rs.randint(1, 8))
+        cell_lo = _cells(rs, nz, ncell)
+        zflags = rs.randint(0, 2, size=ncell)
+        X = rs.randn(n, p) * 2 + rs.randn(1, p) * 10
+        src = rs.randint(0, n, size=(items, nz)).astype(np.int32)
+        rows = rs.randn(items, k, nz)
+        ref = rs.randn(p, k)
+        eng = ProjectionEngine(X)
+        S1 = torch.zeros((p, k), dtype=torch.float64, device=eng.device)
+        S2 = torch.zeros_like(S1)
+        vst, rowsq = eng.item_fused(src, cell_lo, zflags, rows, ref=ref, S1=S1, S2=S2, want_vst=True,
+                                    want_rowsq=True)
+        Z = _zscore_items(X, src, cell_lo, zflags)
+        want = np.einsum("bji,biv->bjv", rows, Z)
+        scale = max(np.abs(want).max(), 1e-300)
+        tag = f"trial {trial}: n={n} p={p} nz={nz} cells={ncell} k={k} items={items}"
+        np.testing.assert_allclose(vst.cpu().numpy(), want, rtol=1e-9, atol=1e-10 * scale, err_msg=tag)
+        np.testing.assert_allclose(rowsq.cpu().numpy(), (want ** 2).sum(-1), rtol=1e-9, atol=1e-18 * scale ** 2,
+                                   err_msg=tag)
+        d = np.transpose(want, (0, 2, 1)) - ref
+        np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-9, atol=1e-9 * (scale + 1), err_msg=tag)
+        np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-9 * (scale + 1) ** 2,
+                                   err_msg=tag)
+
+
+def test_fused_gram_and_latent_random_shapes():
+    import torch
+    from plspy_amd import _lib
+    from plspy_amd.engine import ProjectionEngine, _ptr, _stream
+    rs = np.random.RandomState(12)
+    for trial in range(16):
+        n = int(rs.choice([6, 17, 48, 64, 65, 100, 130]))
+        p = int(rs.choice([7, 64, 200, 1000]))
+        nz = int(rs.randint(4, 120))
+        ncell = int(rs.randint(1, min(nz, 7)))
+        m = int(rs.choice([1, 9, 16, 30, 50]))
+        items = int(rs.randint(1, 8))
+        cell_lo = _cells(rs, nz, ncell)
+        zflags = rs.randint(0, 2, size=ncell)
+        X = rs.randn(n, p) + 3.0
+        src = rs.randint(0, n, size=(items, nz)).astype(np.int32)
+        rows = rs.randn(items, m, nz)
+        eng = ProjectionEngine(X)
+        tag = f"trial {trial}: n={n} p={p} nz={nz} cells={ncell} m={m} items={items}"
+        # Gram with the gather / z-score fused into its staging
+        G = eng.gram_phase(rows, gather=dict(src=src, cell_lo=cell_lo, cell_z=zflags)).cpu().numpy()
+        M = np.einsum("bji,biv->bjv", rows, _zscore_items(X, src, cell_lo, zflags))
+        want = np.einsum("bjv,blv->bjl", M, M)
+        np.testing.assert_allclose(G[:, :m, :m], want, rtol=1e-9, atol=1e-10 * np.abs(want).max(), err_msg=tag)
+        # latent kernel: Zt = VS X^T, nsq = row norms^2 of VS
+        k = min(m, 64)
+        vs = rs.randn(items, k, p)
+        d_vs = eng.dev(vs)
+        need = eng.lib.plsr_latent_workspace_bytes(n, k, items, p)
+        assert need > 0, tag
+        work = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        Zt = torch.empty((items, k, n), dtype=torch.float64, device=eng.device)
+        nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device)
+        _lib.check(eng.lib.plsr_latent(_ptr(eng.X), eng.X.stride(0), p, n, _ptr(d_vs), p, items, k, _ptr(Zt),
+                                       _ptr(nsq), _ptr(work), need, _stream()), "plsr_latent")
+        wantz = np.einsum("bjv,iv->bji", vs, X)
+        np.testing.assert_allclose(Zt.cpu().numpy(), wantz, rtol=1e-9, atol=1e-10 * np.abs(wantz).max(), err_msg=tag)
+        np.testing.assert_allclose(nsq.cpu().numpy(), (vs ** 2).sum(-1), rtol=1e-10, err_msg=tag)
+
+
+def test_projection_phases_random_shapes():
+    """K1 through the engine: permutation norms, bootstrap moments / norms / T and
+    the dumped VS for random n, k (all periods incl. padded ones), R, p."""
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(13)
+    for trial in range(20):
+        n = int(rs.randint(3, 70))
+        p = int(rs.choice([1, 63, 64, 65, 257]))
+        k = int(rs.randint(1, 15))
+        k2 = int(rs.randint(0, 13))
+        R = int(rs.randint(1, 30))
+        X = rs.randn(n, p)
+        M = rs.randn(n, k)
+        inds = rs.randint(0, n, size=(R, n)).astype(np.int32)
+        Xm = rs.randn(k2, p) if k2 else None
+        ref = rs.randn(p, k)
+        eng = ProjectionEngine(X)
+        tag = f"trial {trial}: n={n} p={p} k={k} k2={k2} R={R}"
+        # VS_b = X^T Op_b with Op_b[i] = sum_{r: inds[b,r]=i} M[r]
+        Op = np.zeros((R, n, k))
+        for b in range(R):
+            np.add.at(Op[b], inds[b], M)
+        VS = np.einsum("iv,bik->bvk", X, Op)
+        ssq = eng.perm_phase(k, inds=inds, M=M).cpu().numpy()
+        np.testing.assert_allclose(ssq, (VS ** 2).sum(1), rtol=1e-10, atol=1e-12, err_msg=tag)
+        res = eng.boot_phase(k, inds=inds, M=M, ref=ref, Xm=eng.dev(Xm) if k2 else None, dump=True)
+        np.testing.assert_allclose(res["vs"].cpu().numpy(), VS, rtol=1e-10, atol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(res["ssq"].cpu().numpy(), (VS ** 2).sum(1), rtol=1e-10, atol=1e-12, err_msg=tag)
+        d = VS - ref
+        np.testing.assert_allclose(res["S1"].cpu().numpy(), d.sum(0), rtol=1e-9, atol=1e-10, err_msg=tag)
+        np.testing.assert_allclose(res["S2"].cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-10, err_msg=tag)
+        if k2:
+            T = np.einsum("bvk,cv->bkc", VS, Xm)
+            np.testing.assert_allclose(res["T"].cpu().numpy(), T, rtol=1e-9, atol=1e-10 * (np.abs(T).max() + 1),
+                                       err_msg=tag)
