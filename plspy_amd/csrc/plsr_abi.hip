@@ -255,6 +255,43 @@ int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hi
   }
   return launch_kernel(kern, MODE, a, lds, grid, st);
 }
+// K1r: one wave per workgroup; the batch is split so that the grid has about
+// twenty rounds of the 2048 resident waves (a wave's X fragments cost 4 nk loads
+// per run, so runs should stay tens of tiles long)
+int launch_perm_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
+  int nsplit = (int)std::min<int64_t>(a.ntiles, std::max<int64_t>(1, (20 * 2048 + nvt - 1) / nvt));
+  nsplit = std::min(nsplit, std::max(1, a.ntiles / 8));
+  ProjectKernel kern = nullptr;
+  switch (a.nk) {
+    case 4: kern = project_perm_reg_kernel<4>; break;
+    case 5: kern = project_perm_reg_kernel<5>; break;
+    case 6: kern = project_perm_reg_kernel<6>; break;
+    case 7: kern = project_perm_reg_kernel<7>; break;
+    case 8: kern = project_perm_reg_kernel<8>; break;
+    case 9: kern = project_perm_reg_kernel<9>; break;
+    case 10: kern = project_perm_reg_kernel<10>; break;
+    case 11: kern = project_perm_reg_kernel<11>; break;
+    case 12: kern = project_perm_reg_kernel<12>; break;
+    case 13: kern = project_perm_reg_kernel<13>; break;
+    case 14: kern = project_perm_reg_kernel<14>; break;
+    case 15: kern = project_perm_reg_kernel<15>; break;
+    case 16: kern = project_perm_reg_kernel<16>; break;
+    default: return PLSR_EUNSUPPORTED;
+  }
+  TimedLaunch tl{};
+  if (g_timing) {
+    (void)hipEventCreate(&tl.a);
+    (void)hipEventCreate(&tl.b);
+    tl.kind = 0;
+    (void)hipEventRecord(tl.a, st);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nvt, (unsigned)nsplit), dim3(64), 0, st, a);
+  if (g_timing) {
+    (void)hipEventRecord(tl.b, st);
+    g_timed.push_back(tl);
+  }
+  return check_launch();
+}
 }  // namespace
 
 extern "C" size_t plsr_batch_workspace_bytes(const plsr_layout_t *lay, int64_t p, int32_t k2) {
@@ -291,9 +328,14 @@ extern "C" int plsr_perm_batch(const double *d_X, int64_t ldx, int64_t p, const 
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
   hipStream_t st = (hipStream_t)stream;
-  // the permutation kernel keeps no per-latent-variable registers, so the
-  // period-1 instance serves every k
-  rc = launch_project<0>(a, 1, w.nvt, w.nsplit, st);
+  if (a.nk >= 4 && a.nk <= 16) {
+    // n <= 64: the X fragments of a wave fit its registers (K1r)
+    rc = launch_perm_reg(a, w.nvt, st);
+  } else {
+    // the permutation kernel keeps no per-latent-variable registers, so the
+    // period-1 instance serves every k
+    rc = launch_project<0>(a, 1, w.nvt, w.nsplit, st);
+  }
   if (rc) return rc;
   return reduce_slabs(w.norm_part, w, 1, lay, d_ssq, st);
 }

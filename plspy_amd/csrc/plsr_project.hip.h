@@ -392,6 +392,77 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
   }
 }
 
+// ---------------------------------------------------------------------------
+// K1r: permutation projection with the X fragments resident in REGISTERS.
+//
+// One wave owns 64 voxels for a run of batch tiles.  The product is taken in the
+// transposed orientation, D[voxel][batch column]: the X fragment is the MFMA A
+// operand (A[m = voxel][k = row]; the same lane contents the LDS-fed kernel reads
+// as its B operand) and the operator fragment the B operand (same buffer,
+// unchanged).  With nk <= 16 the 4 x nk X fragments of the wave fit its register
+// file (<= 128 VGPRs), so the k-loop reads nothing but the operator fragments,
+// and those a whole tile ahead (fr[]): the MFMA pipe runs at the register-fed
+// rate (microbench/mfma_f64_regB.hip: 74-75 TFLOP/s at 1-2 waves per SIMD,
+// against 58-71 for one ds_read per MFMA).  In this orientation the column
+// norms are sums over the accumulator's ROW index: 16 FMAs per lane and two
+// cross-lane adds -- no LDS transpose.  No LDS, no barriers, workgroup = wave.
+// (Bootstrap keeps the LDS-fed kernel: its moment sums need the other
+// orientation, and its extra registers do not fit beside the X fragments.)
+template <int NK>
+__global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) {
+  const int lane = threadIdx.x;
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int64_t vt = blockIdx.x;
+  const int64_t v0 = vt * TV;
+
+  double xa[NK][NT];
+#pragma unroll
+  for (int s = 0; s < NK; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = 4 * s + g;
+      const int64_t v = v0 + nt * 16 + col;
+      xa[s][nt] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+    }
+
+  const int per = (A.ntiles + gridDim.y - 1) / gridDim.y;
+  const int t_lo = blockIdx.y * per;
+  const int t_hi = min(A.ntiles, t_lo + per);
+  if (t_lo >= t_hi) return;
+  const int64_t C = (int64_t)A.ntiles * 16;
+
+  double fr[NK];
+  {
+    const double *ap = A.frag + ((size_t)t_lo * NK) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) fr[s] = ap[(size_t)s * 64];
+  }
+  for (int t = t_lo; t < t_hi; ++t) {
+    // next tile's fragments (the last tile of the buffer re-reads itself)
+    const double *an = A.frag + ((size_t)min(t + 1, A.ntiles - 1) * NK) * 64 + lane;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const double b = fr[s];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(xa[s][nt], b, acc[nt]);
+      fr[s] = an[(size_t)s * 64];
+    }
+    // acc[nt][r] = VS[batch column col][voxel 16 nt + g + 4 r]
+    double q = 0.0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q = fma(acc[nt][r], acc[nt][r], q);
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (g == 0) A.norm_part[vt * C + (int64_t)t * 16 + col] = q;
+  }
+}
+
 inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp) {
   size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD + (boot ? nh * 4 * XM_LD + kp * TV : 0)) *
              sizeof(double);
