@@ -195,7 +195,7 @@ def main():
             "end_to_end_resamples_per_s": total / (elapsed + t_index * args.steps / 1.0),
             "host_index_generation_s_per_step": t_index,
             "roofline": {
-                "bound": "mfma", "kernel": "plsr::project_kernel<3, 1, 2> (bootstrap projection)",
+                "bound": "mfma", "kernel": "plsr::project_boot_reg_kernel<15, false, 2> (bootstrap projection, K1br)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": bm, "launches": len(boot_ms),

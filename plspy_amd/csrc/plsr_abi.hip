@@ -64,6 +64,21 @@ extern "C" const char *plsr_strerror(int code) {
 
 extern "C" int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *out) {
   if (!out || n <= 0 || k <= 0 || R <= 0) return PLSR_EINVAL;
+  if ((n + 3) / 4 >= REG_NK_MIN && (n + 3) / 4 <= REG_NK_MAX) {
+    // n <= 64: the register-resident kernels (K1r / K1br) take the batch in
+    // LV-major order -- tile t holds 16 consecutive resamples of latent variable
+    // t / (Rp/16); period 0 marks this layout
+    out->n = n;
+    out->k = k;
+    out->R = R;
+    out->nk = (n + 3) / 4;
+    out->kp = k;
+    out->period = 0;
+    out->Rp = (R + 15) / 16 * 16;
+    out->ntiles = k * (out->Rp / 16);
+    out->frag_elems = (int64_t)out->ntiles * out->nk * 64 + 4 * 64;
+    return PLSR_OK;
+  }
   int kp = k;
   int period = k / std::gcd(4, k);
   if (period > MAX_PERIOD) {
@@ -87,6 +102,8 @@ extern "C" int plsr_layout_init(int32_t n, int32_t k, int32_t R, plsr_layout_t *
 }
 
 static inline int64_t lay_nquads(const plsr_layout_t *l) { return (int64_t)l->kp * (l->Rp / 4); }
+// tiles per latent variable in the LV-major layout (0 = quad layout)
+static inline int lay_tpl(const plsr_layout_t *l) { return l->period == 0 ? l->Rp / 16 : 0; }
 
 static int launch_ops(const int32_t *d_inds, const double *d_M, const double *d_cols,
                       const plsr_layout_t *lay, double *d_frag, void *stream) {
@@ -103,6 +120,7 @@ static int launch_ops(const int32_t *d_inds, const double *d_M, const double *d_
   a.R = lay->R;
   a.nquads = (int32_t)lay_nquads(lay);
   a.ntiles = lay->ntiles;
+  a.tpl = lay_tpl(lay);
   const int64_t total = (int64_t)lay->ntiles * lay->nk * 64;
   dim3 grid((unsigned)((total + 255) / 256));
   if (d_cols)
@@ -131,7 +149,9 @@ namespace {
 constexpr int SLAB_CHUNK = 64;
 
 struct Work {
-  double *mom_part;    // [2][nsplit][p][k]   (boot)
+  double *mom_part;    // [2][nsplit][p][k]   (boot; LV-major layout: [1 + nsplit][p][k])
+  double *opsum;       // [4 nk][k]           (boot, LV-major layout)
+  double *sink;        // [64] store target of idle lanes (register-resident kernels)
   int nsplit;          // column splits of the batch (grid.y)
   double *norm_part;   // [nvt][C]
   double *T_part;      // [nvt][C][k2]
@@ -145,6 +165,13 @@ struct Work {
 // workgroups (256 CUs x 2 resident workgroups), without splitting below one
 // wave x period group per workgroup
 int pick_split(const plsr_layout_t *lay, int64_t nvt) {
+  if (lay->period == 0) {
+    // LV-major layout (K1br): splits per latent variable, for about twenty rounds
+    // of the 2048 resident waves (one wave per workgroup, grid.y = k * splits)
+    const int tpl = lay->Rp / 16;
+    const int64_t want = (20 * 2048 + nvt * lay->k - 1) / (nvt * lay->k);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max(1, tpl / 4)));
+  }
   const int groups = (lay->ntiles + WAVES * lay->period - 1) / (WAVES * lay->period);
   int best = 1;
   double best_eff = 0.0;
@@ -172,6 +199,8 @@ Work carve(const plsr_layout_t *lay, int64_t p, int32_t k2, void *base, bool boo
     return ptr;
   };
   w.mom_part = boot ? take((size_t)2 * w.nsplit * p * lay->k) : nullptr;
+  w.opsum = boot ? take((size_t)4 * lay->nk * lay->k) : nullptr;
+  w.sink = take(64);
   w.norm_part = take((size_t)w.nvt * w.C);
   w.T_part = k2 > 0 ? take((size_t)w.nvt * w.C * k2) : nullptr;
   w.lvl2 = take((size_t)w.nchunk * w.C * std::max(1, (int)k2));
@@ -187,7 +216,7 @@ int reduce_slabs(const double *slabs, const Work &w, int width, const plsr_layou
                      SLAB_CHUNK);
   dim3 g2((unsigned)((E + 255) / 256));
   hipLaunchKernelGGL(slab_final_kernel, g2, dim3(256), 0, st, (const double *)w.lvl2, d_out, w.C,
-                     width, w.nchunk, lay->kp, lay->k, lay->R, (int)lay_nquads(lay));
+                     width, w.nchunk, lay->kp, lay->k, lay->R, (int)lay_nquads(lay), lay_tpl(lay));
   return check_launch();
 }
 
@@ -255,6 +284,49 @@ int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hi
   }
   return launch_kernel(kern, MODE, a, lds, grid, st);
 }
+template <bool DUMP, int NHT>
+ProjectKernel boot_reg_instance(int nk) {
+  switch (nk) {
+    case 4: return project_boot_reg_kernel<4, DUMP, NHT>;
+    case 5: return project_boot_reg_kernel<5, DUMP, NHT>;
+    case 6: return project_boot_reg_kernel<6, DUMP, NHT>;
+    case 7: return project_boot_reg_kernel<7, DUMP, NHT>;
+    case 8: return project_boot_reg_kernel<8, DUMP, NHT>;
+    case 9: return project_boot_reg_kernel<9, DUMP, NHT>;
+    case 10: return project_boot_reg_kernel<10, DUMP, NHT>;
+    case 11: return project_boot_reg_kernel<11, DUMP, NHT>;
+    case 12: return project_boot_reg_kernel<12, DUMP, NHT>;
+    case 13: return project_boot_reg_kernel<13, DUMP, NHT>;
+    case 14: return project_boot_reg_kernel<14, DUMP, NHT>;
+    case 15: return project_boot_reg_kernel<15, DUMP, NHT>;
+    case 16: return project_boot_reg_kernel<16, DUMP, NHT>;
+    default: return nullptr;
+  }
+}
+
+int launch_boot_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
+  const int nh = (a.k2 + 3) / 4;
+  ProjectKernel kern = a.vs_dump ? boot_reg_instance<true, -1>(a.nk)
+                       : nh == 1 ? boot_reg_instance<false, 1>(a.nk)
+                       : nh == 2 ? boot_reg_instance<false, 2>(a.nk)
+                                 : boot_reg_instance<false, -1>(a.nk);
+  if (!kern) return PLSR_EUNSUPPORTED;
+  const size_t lds = ((size_t)((a.k2 + 3) / 4) * 4 * XM_LD + 16 * 64) * sizeof(double);
+  TimedLaunch tl{};
+  if (g_timing) {
+    (void)hipEventCreate(&tl.a);
+    (void)hipEventCreate(&tl.b);
+    tl.kind = 1;
+    (void)hipEventRecord(tl.a, st);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nvt, (unsigned)(a.k * a.msplit)), dim3(64), lds, st, a);
+  if (g_timing) {
+    (void)hipEventRecord(tl.b, st);
+    g_timed.push_back(tl);
+  }
+  return check_launch();
+}
+
 // K1r: one wave per workgroup; the batch is split so that the grid has about
 // twenty rounds of the 2048 resident waves (a wave's X fragments cost 4 nk loads
 // per run, so runs should stay tens of tiles long)
@@ -327,6 +399,7 @@ extern "C" int plsr_perm_batch(const double *d_X, int64_t ldx, int64_t p, const 
   Work w = carve(lay, p, 0, d_work, false);
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
+  a.sink = w.sink;
   hipStream_t st = (hipStream_t)stream;
   if (a.nk >= 4 && a.nk <= 16) {
     // n <= 64: the X fragments of a wave fit its registers (K1r)
@@ -351,7 +424,7 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   if (!d_S1 || !d_S2 || !d_ssq || !d_work) return PLSR_EINVAL;
   if (k2 < 0 || k2 > 16) return PLSR_EUNSUPPORTED;
   if (k2 > 0 && (!d_Xm || !d_T || ldxm < p)) return PLSR_EINVAL;
-  if (lay->period < 1 || lay->period > MAX_PERIOD) return PLSR_EUNSUPPORTED;
+  if (lay->period < 0 || lay->period > MAX_PERIOD) return PLSR_EUNSUPPORTED;
   Work w = carve(lay, p, k2, d_work, true);
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
@@ -369,8 +442,22 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
     rc = chain(g_tail, st);
     if (rc) return rc;
   }
-  rc = d_vs_dump ? launch_project<2>(a, lay->period, w.nvt, w.nsplit, st)
-                 : launch_project<1>(a, lay->period, w.nvt, w.nsplit, st);
+  const bool reg = lay->period == 0;
+  if (reg) {
+    // K1br: plain moment partials P1 [p][k], P2 [splits][p][k]; summed operator first
+    a.S1 = w.mom_part;
+    a.S2 = w.mom_part + (size_t)p * lay->k;
+    a.tpl = lay_tpl(lay);
+    a.msplit = w.nsplit;
+    a.opsum = w.opsum;
+    a.sink = w.sink;
+    hipLaunchKernelGGL(opsum_kernel, dim3((unsigned)lay->nk, (unsigned)lay->k), dim3(256), 0, st, d_frag, w.opsum,
+                       lay->nk, lay->k, a.tpl);
+    rc = launch_boot_reg(a, w.nvt, st);
+  } else {
+    rc = d_vs_dump ? launch_project<2>(a, lay->period, w.nvt, w.nsplit, st)
+                   : launch_project<1>(a, lay->period, w.nvt, w.nsplit, st);
+  }
   if (rc) return rc;
   if (g_tail) {
     // merges and slab reductions follow the projection on the tail stream
@@ -378,7 +465,12 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
     if (rc) return rc;
     st = g_tail;
   }
-  {
+  if (reg) {
+    const int64_t cnt = p * lay->k;
+    dim3 g((unsigned)((cnt + 255) / 256));
+    hipLaunchKernelGGL(moment_shift_merge_kernel, g, dim3(256), 0, st, d_S1, d_S2, (const double *)a.S1,
+                       (const double *)a.S2, d_ref, cnt, w.nsplit, (double)lay->R);
+  } else {
     const int64_t cnt = p * lay->k;
     dim3 g((unsigned)((cnt + 255) / 256));
     hipLaunchKernelGGL(moment_merge_kernel, g, dim3(256), 0, st, d_S1, (const double *)a.S1, cnt,

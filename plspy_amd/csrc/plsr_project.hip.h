@@ -38,6 +38,7 @@ constexpr int DT_LD = 18;      // padded row of the per-wave 16 x 16 transpose p
 constexpr int XM_LD = 72;      // padded row of the cell-mean tile
 constexpr int WAVES = 4;
 constexpr int MAX_PERIOD = 6;
+constexpr int REG_NK_MIN = 4, REG_NK_MAX = 16;   // k-steps for which the X fragments of a wave fit its registers
 
 struct ProjectArgs {
   const double *X;      // [n][ldx]
@@ -55,6 +56,10 @@ struct ProjectArgs {
   int32_t k2;
   double *S1, *S2;      // [column split][p][k] partial moment sums (overwritten)
   double *vs_dump;      // [R][p][k] or null
+  // register-resident bootstrap kernel (LV-major layout)
+  int32_t tpl, msplit;  // tiles per latent variable; splits of a latent variable's tiles (grid.y = k * msplit)
+  const double *opsum;  // [4 nk][k] sum over the batch of the operators (S1 by linearity)
+  double *sink;         // [64] scratch target of the lanes that have nothing to store (see K1r)
 };
 
 __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
@@ -459,8 +464,239 @@ __global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) 
       for (int r = 0; r < 4; ++r) q = fma(acc[nt][r], acc[nt][r], q);
     q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 32);
-    if (g == 0) A.norm_part[vt * C + (int64_t)t * 16 + col] = q;
+    // every lane stores (the idle ones into a sink): a store under a branch would
+    // make the next tile's first MFMA wait for vmcnt(0), i.e. for this store's
+    // acknowledgement, because the fragment loads share the counter
+    double *dst = g == 0 ? A.norm_part + (vt * C + (int64_t)t * 16 + col) : A.sink + lane;
+    *dst = q;
   }
+}
+
+// ---------------------------------------------------------------------------
+// K1br: bootstrap projection with register-resident X fragments.
+//
+// Same orientation as K1r (D[voxel][batch column]); the batch is in LV-major
+// order (tile = 16 resamples of one latent variable) and a wave's run of tiles
+// stays inside one latent variable j (grid.y = k * msplit), so that
+//   * sum_b VS^2 (second moment) accumulates per lane in 16 registers over the
+//     whole run and is folded over the 16 column lanes once, at the end;
+//   * sum_b VS (first moment) needs no accumulation at all: it is linear,
+//     X^T (sum_b Op_b), formed from the wave's own X registers and the summed
+//     operator (A.opsum) by the split that owns the variable's first tiles;
+//   * the column norms are sums over the accumulator's row index (registers + two
+//     cross-lane adds) and the product with the cell means (Tdistrib) takes the
+//     accumulator registers directly as the B operand of v_mfma_f64_4x4x4_4b
+//     (B_b[k][j]: k = voxel, j = batch column) -- no LDS transpose anywhere.
+// Moments are plain sums (zero-padded columns contribute nothing); the shift by
+// the observed VS is applied at the merge (moment_unshift_kernel).
+// LDS (per wave = per workgroup): the 64 voxels of the cell means [4 nh][XM_LD] and the
+// second-moment accumulators [16][64] (lane-private slots; in registers they
+// pushed the nk >= 12 instances into scratch).
+// NHT: number of four-cell groups of the second matrix at compile time (-1: from the
+// arguments); with it the tile loop has no branch at all, which is what lets the
+// compiler keep the fragment loads in flight across the loop's back-edge.
+template <int NK, bool DUMP, int NHT>
+__global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int64_t vt = blockIdx.x;
+  const int64_t v0 = vt * TV;
+  const int j = blockIdx.y / A.msplit;         // latent variable of this run
+  const int mi = blockIdx.y % A.msplit;
+  const int nh = NHT >= 0 ? NHT : (A.k2 + 3) / 4;
+
+  double xa[NK][NT];
+#pragma unroll
+  for (int s = 0; s < NK; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = 4 * s + g;
+      const int64_t v = v0 + nt * 16 + col;
+      xa[s][nt] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
+    }
+  for (int cell = 0; cell < 4 * nh; ++cell) {
+    const int64_t v = v0 + lane;
+    smem[cell * XM_LD + lane] = (cell < A.k2 && v < A.p) ? A.Xm[(int64_t)cell * A.ldxm + v] : 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const int per = (A.tpl + A.msplit - 1) / A.msplit;
+  const int t_lo = j * A.tpl + min(A.tpl, mi * per);
+  const int t_hi = j * A.tpl + min(A.tpl, mi * per + per);
+  const int64_t C = (int64_t)A.ntiles * 16;
+
+  double *s2 = smem + 4 * nh * XM_LD + lane;          // s2[(4 nt + r) * 64]
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) s2[i * 64] = 0.0;
+
+  double fr[NK];
+  {
+    const double *ap = A.frag + ((size_t)min(t_lo, A.ntiles - 1) * NK) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) fr[s] = ap[(size_t)s * 64];
+  }
+  for (int t = t_lo; t < t_hi; ++t) {
+    const double *an = A.frag + ((size_t)min(t + 1, A.ntiles - 1) * NK) * 64 + lane;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const double b = fr[s];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(xa[s][nt], b, acc[nt]);
+      fr[s] = an[(size_t)s * 64];
+    }
+    // acc[nt][r] = VS_b[voxel 16 nt + g + 4 r][j],  b = 16 (t - j tpl) + col
+    // (scheduling barriers keep the epilogue's LDS operands from being hoisted all
+    // at once next to the resident X fragments: that spilled)
+    double q = 0.0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double sq = acc[nt][r] * acc[nt][r];
+        // ds_add_f64 without return: lane-private slot, so the order of additions is
+        // program order (deterministic), and no register or wait is spent on it
+        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(s2 + (4 * nt + r) * 64), sq);
+        q += sq;
+      }
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    // stores are unconditional (idle lanes write a sink, see K1r) and fixed in number,
+    // so the compiler can count them and the fragment loads apart (no vmcnt(0) per tile)
+    {
+      double *dst = g == 0 ? A.norm_part + (vt * C + (int64_t)t * 16 + col) : A.sink + lane;
+      *dst = q;
+    }
+    double Tout[4] = {0.0, 0.0, 0.0, 0.0};
+    // (straight-line code under uniform guards, not a loop: a child loop in the tile
+    // loop makes the compiler wait for vmcnt(0) at the tile loop's header)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h >= nh) continue;
+      // T[cell 4 h + i][column 4 b + jj] lands at lane 16 i + 4 b + jj = (g = i, col).
+      // Four independent accumulation chains (one per voxel tile): a single chain of
+      // sixteen dependent 4x4x4 MFMAs would expose the MFMA latency sixteen times.
+      // The cell-mean operands of group r + 1 are read while group r multiplies.
+      double aT[NT] = {0.0, 0.0, 0.0, 0.0};
+      const double *xm = smem + (4 * h + (lane & 3)) * XM_LD + g;
+      double xn[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xn[nt] = xm[16 * nt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double xc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xc[nt] = xn[nt];
+        if (r < 3) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) xn[nt] = xm[16 * nt + 4 * (r + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          aT[nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(xc[nt], acc[nt][r], aT[nt], 0, 0, 0);
+      }
+      Tout[h] = (aT[0] + aT[1]) + (aT[2] + aT[3]);
+    }
+    {
+      double *tp = A.T_part + (vt * C + (int64_t)t * 16 + col) * A.k2;     // never dereferenced when k2 = 0
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int cell = 4 * h + g;
+        double *dst = cell < A.k2 ? tp + cell : A.sink + lane;
+        *dst = Tout[h];
+      }
+    }
+    if (DUMP) {
+      const int64_t b = (int64_t)(t - j * A.tpl) * 16 + col;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t v = v0 + nt * 16 + g + 4 * r;
+          if (b < A.R && v < A.p) A.vs_dump[(b * A.p + v) * A.k + j] = acc[nt][r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- second moment: fold the 16 column lanes, one store per (voxel, j) ----
+  double *o2 = A.S2 + (int64_t)mi * A.p * A.k;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x = s2[(4 * nt + r) * 64];
+      x += __shfl_xor(x, 1);
+      x += __shfl_xor(x, 2);
+      x += __shfl_xor(x, 4);
+      x += __shfl_xor(x, 8);
+      const int64_t v = v0 + nt * 16 + g + 4 * r;
+      if (col == 0 && v < A.p) o2[v * A.k + j] = x;
+    }
+  // ---- first moment by linearity (the split that owns the variable's first tiles) ----
+  if (mi == 0) {
+    double a1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) a1[nt] = 0.0;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const double os = A.opsum[(int64_t)(4 * s + g) * A.k + j];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) a1[nt] = fma(xa[s][nt], os, a1[nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      double x = a1[nt];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      const int64_t v = v0 + nt * 16 + col;
+      if (g == 0 && v < A.p) A.S1[v * A.k + j] = x;
+    }
+  }
+}
+
+// opsum[i][j] = sum over the batch of Op_b[i][j], from the LV-major fragments
+// (frag[t][s][lane]: lane (g, m) holds Op of resample 16 (t % tpl) + m, variable t / tpl, row 4 s + g).
+// One workgroup per (k-step s, variable j); its four waves split the variable's tiles.
+__global__ __launch_bounds__(256) void opsum_kernel(const double *frag, double *opsum, int nk, int k, int tpl) {
+  __shared__ double part[WAVES][4];
+  const int s = blockIdx.x, j = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double a = 0.0;
+  for (int tt = wave; tt < tpl; tt += WAVES) a += frag[((size_t)(j * tpl + tt) * nk + s) * 64 + lane];
+  a += __shfl_xor(a, 1);
+  a += __shfl_xor(a, 2);
+  a += __shfl_xor(a, 4);
+  a += __shfl_xor(a, 8);
+  if ((lane & 15) == 0) part[wave][lane >> 4] = a;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int g = threadIdx.x;
+    opsum[(int64_t)(4 * s + g) * k + j] = (part[0][g] + part[1][g]) + (part[2][g] + part[3][g]);
+  }
+}
+
+// S1 += P1 - cnt * ref,  S2 += sum_c P2[c] - 2 ref P1 + cnt ref^2   (plain sums -> shifted sums)
+__global__ __launch_bounds__(256) void moment_shift_merge_kernel(double *S1, double *S2, const double *P1,
+                                                                const double *P2, const double *ref,
+                                                                int64_t count, int nsplit, double cnt) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  const double a = P1[e];
+  double b = P2[e];
+  for (int c = 1; c < nsplit; ++c) b += P2[(int64_t)c * count + e];
+  const double r = ref != nullptr ? ref[e] : 0.0;
+  S1[e] += a - cnt * r;
+  S2[e] += fma(r, fma(cnt, r, -2.0 * a), b);
 }
 
 inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp) {
@@ -479,6 +715,7 @@ struct OpsArgs {
   const double *cols;    // [R][k][n]         (dense mode)
   double *frag;          // [ntiles][nk][64]
   int32_t n, nk, k, kp, R, nquads, ntiles;
+  int32_t tpl;           // > 0: LV-major layout, tiles per latent variable
 };
 
 template <bool DENSE>
@@ -491,9 +728,16 @@ __global__ __launch_bounds__(256) void ops_kernel(OpsArgs A) {
   const int t = (int)((e >> 6) / A.nk);
   const int m = lane & 15;
   const int i = 4 * s + (lane >> 4);
-  const int q = 4 * t + (m & 3);
-  const int j = q % A.kp;
-  const int b = 4 * (q / A.kp) + (m >> 2);
+  int q, j, b;
+  if (A.tpl > 0) {               // LV-major: tile t = 16 resamples of latent variable t / tpl
+    q = 0;
+    j = t / A.tpl;
+    b = (t % A.tpl) * 16 + m;
+  } else {                       // quad layout
+    q = 4 * t + (m & 3);
+    j = q % A.kp;
+    b = 4 * (q / A.kp) + (m >> 2);
+  }
   double val = 0.0;
   if (q < A.nquads && j < A.k && b < A.R && i < A.n) {
     if (DENSE) {
@@ -534,15 +778,23 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const double *in, double 
 // resample-major [R][k][w]
 __global__ __launch_bounds__(256) void slab_final_kernel(const double *in, double *out, int64_t C,
                                                          int w, int nslab, int kp, int k, int R,
-                                                         int nquads) {
+                                                         int nquads, int tpl) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= C * w) return;
   const int64_t c = e / w;
   const int cc = (int)(e % w);
   const int m = (int)(c & 15);
-  const int64_t q = 4 * (c >> 4) + (m & 3);
-  const int j = (int)(q % kp);
-  const int64_t b = 4 * (q / kp) + (m >> 2);
+  int64_t q, b;
+  int j;
+  if (tpl > 0) {
+    q = 0;
+    j = (int)((c >> 4) / tpl);
+    b = ((c >> 4) % tpl) * 16 + m;
+  } else {
+    q = 4 * (c >> 4) + (m & 3);
+    j = (int)(q % kp);
+    b = 4 * (q / kp) + (m >> 2);
+  }
   if (q >= nquads || j >= k || b >= R) return;
   double a = 0.0;
   for (int s = 0; s < nslab; ++s) a += in[(int64_t)s * C * w + e];

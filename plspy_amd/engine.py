@@ -65,12 +65,15 @@ class ProjectionEngine:
         return lay
 
     def batch_size(self, k, k2, R):
-        """Largest multiple-of-4 batch whose scratch fits work_limit."""
-        lay = self.layout(k, 4)
-        per4 = self.lib.plsr_batch_workspace_bytes(ctypes.byref(lay), self.p, k2)
-        per4 += lay.frag_elems * 8
-        nb = max(1, self.work_limit // max(per4, 1))
-        return int(min((R + 3) // 4 * 4, nb * 4))
+        """Largest batch (a multiple of 16 resamples, or all of them) whose
+        scratch fits work_limit."""
+        b = int(R)
+        while True:
+            lay = self.layout(k, b)
+            need = self.lib.plsr_batch_workspace_bytes(ctypes.byref(lay), self.p, k2) + lay.frag_elems * 8
+            if need <= self.work_limit or b <= 16:
+                return b
+            b = max(16, (b // 2 + 15) // 16 * 16)
 
     def _scratch(self, lay, k2, lane=None):
         L = self._lanes.get(lane)

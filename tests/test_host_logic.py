@@ -35,12 +35,24 @@ def test_abi_exports_every_declared_symbol(lib):
 @pytest.mark.parametrize("k,kp,period", [(1, 1, 1), (2, 2, 1), (3, 3, 3), (4, 4, 1), (5, 5, 5),
                                          (6, 6, 3), (7, 8, 2), (9, 12, 3), (12, 12, 3), (24, 24, 6)])
 def test_layout(lib, k, kp, period):
+    """Quad layout (n > 64: the LDS-fed kernels)."""
     lay = _lib.Layout()
-    assert lib.plsr_layout_init(60, k, 10, ctypes.byref(lay)) == 0
-    assert (lay.kp, lay.period, lay.nk, lay.Rp) == (kp, period, 15, 12)
+    assert lib.plsr_layout_init(100, k, 10, ctypes.byref(lay)) == 0
+    assert (lay.kp, lay.period, lay.nk, lay.Rp) == (kp, period, 25, 12)
     assert (4 * lay.period) % lay.kp == 0          # the slot -> latent-variable map repeats
     assert lay.ntiles == -(-(lay.kp * lay.Rp // 4) // 4)
     assert lay.frag_elems == lay.ntiles * lay.nk * 64 + 4 * 64      # + prefetch padding
+
+
+@pytest.mark.parametrize("n,k,R", [(60, 6, 10), (13, 1, 16), (64, 7, 1000), (16, 24, 17)])
+def test_layout_lv_major(lib, n, k, R):
+    """n <= 64 (4..16 k-steps): LV-major layout of the register-resident kernels,
+    marked by period 0 -- tile t = 16 consecutive resamples of latent variable t / (Rp/16)."""
+    lay = _lib.Layout()
+    assert lib.plsr_layout_init(n, k, R, ctypes.byref(lay)) == 0
+    assert (lay.kp, lay.period, lay.nk) == (k, 0, -(-n // 4))
+    assert lay.Rp == -(-R // 16) * 16 and lay.ntiles == k * lay.Rp // 16
+    assert lay.frag_elems == lay.ntiles * lay.nk * 64 + 4 * 64
 
 
 def test_layout_rejects(lib):

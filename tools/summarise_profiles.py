@@ -35,7 +35,8 @@ for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             pmc[k]["launches"] = cnt[k]
 if pmc:
     json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
-    boot = [k for k in pmc if "project_kernel<3, 1" in k]
+    boot = [k for k in pmc if "project_boot_reg_kernel" in k and "false" in k] or \
+           [k for k in pmc if "project_kernel<3, 1" in k]
     if boot:
         b = pmc[boot[0]]
         fetch = b.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024
@@ -58,7 +59,7 @@ tr = glob.glob(os.path.join(src, "stats", "*kernel_trace.csv"))
 if tr:
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
-        if "project_kernel" in r["Kernel_Name"]:
+        if "project_" in r["Kernel_Name"]:
             per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     line = [l for l in open(os.path.join(src, "stats.log")) if l.startswith("{")]
     out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu",
