@@ -123,8 +123,11 @@ static int launch_ops(const int32_t *d_inds, const double *d_M, const double *d_
   a.tpl = lay_tpl(lay);
   const int64_t total = (int64_t)lay->ntiles * lay->nk * 64;
   dim3 grid((unsigned)((total + 255) / 256));
+  const size_t lds_sel = (size_t)16 * lay->n * (sizeof(double) + sizeof(int32_t));
   if (d_cols)
     hipLaunchKernelGGL(ops_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (lds_sel <= 64 * 1024)
+    hipLaunchKernelGGL(ops_select_kernel, dim3((unsigned)lay->ntiles), dim3(256), lds_sel, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(ops_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return check_launch();

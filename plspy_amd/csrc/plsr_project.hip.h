@@ -751,6 +751,47 @@ __global__ __launch_bounds__(256) void ops_kernel(OpsArgs A) {
   A.frag[e] = val;
 }
 
+// Index-select operators, one workgroup per tile: the index vectors and the
+// columns of M that the tile's 16 batch columns need are staged in LDS once, so
+// the n-long scan per fragment element reads LDS instead of global memory (same
+// summation order as ops_kernel<false>, hence bit-identical fragments).
+// LDS: 16 x n ints + 16 x n doubles.
+__global__ __launch_bounds__(256) void ops_select_kernel(OpsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *Mc = smem;                                   // [16][n]
+  int32_t *Is = (int32_t *)(smem + 16 * A.n);          // [16][n]
+  const int t = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 16 * A.n; e += 256) {
+    const int m = e / A.n, r = e - m * A.n;
+    int q, j, b;
+    if (A.tpl > 0) {
+      q = 0;
+      j = t / A.tpl;
+      b = (t % A.tpl) * 16 + m;
+    } else {
+      q = 4 * t + (m & 3);
+      j = q % A.kp;
+      b = 4 * (q / A.kp) + (m >> 2);
+    }
+    const bool live = q < A.nquads && j < A.k && b < A.R;
+    Is[e] = live ? A.inds[(int64_t)b * A.n + r] : -1;
+    Mc[e] = live ? A.M[(int64_t)r * A.k + j] : 0.0;
+  }
+  __syncthreads();
+  for (int o = tid; o < A.nk * 64; o += 256) {
+    const int lane = o & 63, s = o >> 6;
+    const int m = lane & 15;
+    const int i = 4 * s + (lane >> 4);
+    const int32_t *ib = Is + m * A.n;
+    const double *mc = Mc + m * A.n;
+    double val = 0.0;
+    for (int r = 0; r < A.n; ++r)
+      if (ib[r] == i) val += mc[r];
+    A.frag[(int64_t)t * A.nk * 64 + o] = val;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // slab reductions (deterministic, two-level)
 // ---------------------------------------------------------------------------
@@ -796,9 +837,18 @@ __global__ __launch_bounds__(256) void slab_final_kernel(const double *in, doubl
     b = 4 * (q / kp) + (m >> 2);
   }
   if (q >= nquads || j >= k || b >= R) return;
-  double a = 0.0;
-  for (int s = 0; s < nslab; ++s) a += in[(int64_t)s * C * w + e];
-  out[(b * k + j) * w + cc] = a;
+  // four loads in flight (a single dependent chain over ~50 slabs is latency-bound)
+  const int64_t stride = C * w;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int s = 0;
+  for (; s + 3 < nslab; s += 4) {
+    a0 += in[(int64_t)s * stride + e];
+    a1 += in[(int64_t)(s + 1) * stride + e];
+    a2 += in[(int64_t)(s + 2) * stride + e];
+    a3 += in[(int64_t)(s + 3) * stride + e];
+  }
+  for (; s < nslab; ++s) a0 += in[(int64_t)s * stride + e];
+  out[(b * k + j) * w + cc] = (a0 + a1) + (a2 + a3);
 }
 
 // S[e] += sum over column splits of part[c][e]  (fixed order)
