@@ -50,13 +50,30 @@ class ProjectionEngine:
         self.work_limit = int(work_limit)
         self._lanes = {}
         self._tail = None
+        self._h2d = None
 
     # -- helpers -----------------------------------------------------------
     def dev(self, a, dtype=torch.float64):
+        """Device copy of a host array (or the tensor itself if it is already
+        there).  Host arrays are uploaded on a dedicated copy stream: a pageable
+        copy on the compute stream would block the host until every kernel
+        enqueued before it has finished, so the host could never prepare batch
+        i + 1 while the device works on batch i."""
         if a is None:
             return None
-        return torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(
-            device=self.device, dtype=dtype).contiguous()
+        if isinstance(a, np.ndarray):
+            src = torch.from_numpy(np.ascontiguousarray(a))
+            if src.dtype != dtype:
+                src = src.to(dtype)
+            if self._h2d is None:
+                self._h2d = torch.cuda.Stream(device=self.device)
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self._h2d):
+                t = src.to(self.device)
+            cur.wait_stream(self._h2d)
+            t.record_stream(cur)
+            return t
+        return torch.as_tensor(a).to(device=self.device, dtype=dtype).contiguous()
 
     def layout(self, k, R):
         lay = _lib.Layout()
