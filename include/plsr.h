@@ -81,6 +81,17 @@ int plsr_ops_from_indices(const int32_t *d_inds, const double *d_M,
  */
 int plsr_ops_pack(const double *d_cols, const plsr_layout_t *lay, double *d_frag,
                   void *stream);
+/*
+ * Behaviour-PLS operators from the per-cell z-scored behaviour block of every
+ * resample (class_functions.py:240-242 folded with `@ U`, as used at
+ * bootstrap_permutation.py:404):
+ *   Op_b[i][j] = sum_beh Yz[b][i][beh] * U[cell(i)*nb + beh][j]
+ * d_Yz [R][n][nb], d_U [ncell*nb][k], d_rowcell [n] int32 (cell of every row);
+ * the R x k x n operator columns are never formed on the host.
+ */
+int plsr_ops_from_behaviour(const double *d_Yz, int32_t nb, const double *d_U,
+                            const int32_t *d_rowcell, const plsr_layout_t *lay, double *d_frag,
+                            void *stream);
 
 /* Bytes of scratch the two batch calls below need for p voxels. */
 size_t plsr_batch_workspace_bytes(const plsr_layout_t *lay, int64_t p, int32_t k2);

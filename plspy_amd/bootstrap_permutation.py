@@ -165,11 +165,13 @@ class _ResampleTestPLS(ResampleTest):
     # shared pieces
     # ------------------------------------------------------------------
     @staticmethod
-    def _run_perm(eng, k, niter, inds=None, M=None, cols=None):
+    def _run_perm(eng, k, niter, inds=None, M=None, cols=None, beh=None):
         """Shard the phase's resamples, run the permutation kernel, gather."""
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
-        if cols is not None:
+        if beh is not None:
+            ssq = eng.perm_phase(k, beh=(beh[0][lo:hi], beh[1], beh[2]))
+        elif cols is not None:
             ssq = eng.perm_phase(k, cols=cols[lo:hi])
         else:
             ssq = eng.perm_phase(k, inds=inds[lo:hi], M=M)
@@ -257,11 +259,10 @@ class _ResampleTestPLS(ResampleTest):
         Xz = eng.gather_zscore(np.arange(n), bounds, np.ones(len(bounds) - 1))[0]
         eng_z = ProjectionEngine(Xz, device=eng.device, work_limit=eng.work_limit)
         # operator column (b, j)[i] = sum_beh Yz_b[i, beh] * U[(cell(i), beh), j]
+        # (the R x k x n operators are formed on the device from Yz and U)
         Yz = cf.zscore_cells(Y[perms], bounds)                                 # R x n x b
-        cols = np.empty((niter, k, n))
-        for c, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
-            cols[:, :, lo:hi] = np.swapaxes(Yz[:, lo:hi] @ U[c * b:(c + 1) * b], 1, 2)     # (r,i,b)(b,j) -> r,j,i
-        s_hat = np.sqrt(self._run_perm(eng_z, k, niter, cols=cols))
+        rowcell = np.repeat(np.arange(len(bounds) - 1), np.diff(bounds)).astype(np.int32)
+        s_hat = np.sqrt(self._run_perm(eng_z, k, niter, beh=(Yz, U, rowcell)))
         if self._C is None:
             s_hat[np.abs(s_hat) < threshold] = 0
         ratio, step = self._ratios(s_hat, s, np.copy(s), niter)

@@ -139,6 +139,31 @@ extern "C" int plsr_ops_from_indices(const int32_t *d_inds, const double *d_M,
   return launch_ops(d_inds, d_M, nullptr, lay, d_frag, stream);
 }
 
+extern "C" int plsr_ops_from_behaviour(const double *d_Yz, int32_t nb, const double *d_U,
+                                       const int32_t *d_rowcell, const plsr_layout_t *lay, double *d_frag,
+                                       void *stream) {
+  if (!d_Yz || !d_U || !d_rowcell || !lay || !d_frag || nb <= 0) return PLSR_EINVAL;
+  OpsBehArgs b;
+  b.Yz = d_Yz;
+  b.U = d_U;
+  b.rowcell = d_rowcell;
+  b.nb = nb;
+  b.o = OpsArgs{};
+  b.o.frag = d_frag;
+  b.o.n = lay->n;
+  b.o.nk = lay->nk;
+  b.o.k = lay->k;
+  b.o.kp = lay->kp;
+  b.o.R = lay->R;
+  b.o.nquads = (int32_t)lay_nquads(lay);
+  b.o.ntiles = lay->ntiles;
+  b.o.tpl = lay_tpl(lay);
+  const int64_t total = (int64_t)lay->ntiles * lay->nk * 64;
+  hipLaunchKernelGGL(ops_behaviour_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, b);
+  return check_launch();
+}
+
 extern "C" int plsr_ops_pack(const double *d_cols, const plsr_layout_t *lay, double *d_frag,
                              void *stream) {
   if (!d_cols) return PLSR_EINVAL;

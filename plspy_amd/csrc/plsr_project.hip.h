@@ -751,6 +751,47 @@ __global__ __launch_bounds__(256) void ops_kernel(OpsArgs A) {
   A.frag[e] = val;
 }
 
+// Behaviour-PLS operators straight from the z-scored behaviour block
+// (class_functions.py:240-242 folded with `@ U`, bootstrap_permutation.py:404):
+//   Op_b[i][j] = sum_beh Yz[b][i][beh] * U[cell(i) * nb + beh][j]
+// -- the R x k x n operator columns are never built on the host.
+struct OpsBehArgs {
+  const double *Yz;        // [R][n][nb] per-cell z-scored behaviour of every resample
+  const double *U;         // [ncell * nb][k]
+  const int32_t *rowcell;  // [n]
+  int32_t nb;
+  OpsArgs o;               // layout fields (inds / M / cols unused)
+};
+
+__global__ __launch_bounds__(256) void ops_behaviour_kernel(OpsBehArgs B) {
+  const OpsArgs &A = B.o;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)A.ntiles * A.nk * 64;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  const int s = (int)((e >> 6) % A.nk);
+  const int t = (int)((e >> 6) / A.nk);
+  const int m = lane & 15;
+  const int i = 4 * s + (lane >> 4);
+  int q, j, b;
+  if (A.tpl > 0) {
+    q = 0;
+    j = t / A.tpl;
+    b = (t % A.tpl) * 16 + m;
+  } else {
+    q = 4 * t + (m & 3);
+    j = q % A.kp;
+    b = 4 * (q / A.kp) + (m >> 2);
+  }
+  double val = 0.0;
+  if (q < A.nquads && j < A.k && b < A.R && i < A.n) {
+    const double *y = B.Yz + ((int64_t)b * A.n + i) * B.nb;
+    const double *u = B.U + (int64_t)B.rowcell[i] * B.nb * A.k + j;
+    for (int h = 0; h < B.nb; ++h) val = fma(y[h], u[(int64_t)h * A.k], val);
+  }
+  A.frag[e] = val;
+}
+
 // Index-select operators, one workgroup per tile: the index vectors and the
 // columns of M that the tile's 16 batch columns need are staged in LDS once, so
 // the n-long scan per fragment element reads LDS instead of global memory (same

@@ -112,8 +112,13 @@ class ProjectionEngine:
         if self._tail is not None:
             torch.cuda.current_stream().wait_stream(self._tail)
 
-    def _build_ops(self, lay, frag, inds=None, M=None, cols=None):
-        if cols is not None:
+    def _build_ops(self, lay, frag, inds=None, M=None, cols=None, beh=None):
+        if beh is not None:
+            Yz, U, rowcell = beh
+            _lib.check(self.lib.plsr_ops_from_behaviour(_ptr(Yz), int(Yz.shape[2]), _ptr(U), _ptr(rowcell),
+                                                        ctypes.byref(lay), _ptr(frag), _stream()),
+                       "plsr_ops_from_behaviour")
+        elif cols is not None:
             _lib.check(self.lib.plsr_ops_pack(_ptr(cols), ctypes.byref(lay), _ptr(frag), _stream()),
                        "plsr_ops_pack")
         else:
@@ -122,10 +127,12 @@ class ProjectionEngine:
                        "plsr_ops_from_indices")
 
     # -- permutation ---------------------------------------------------------
-    def perm_phase(self, k, inds=None, M=None, cols=None):
+    def perm_phase(self, k, inds=None, M=None, cols=None, beh=None):
         """s_hat^2 (R x k) for every resample.  Either ``inds`` (R x n int32
-        row selections) with ``M`` (n x k), or dense ``cols`` (R x k x n)."""
-        R = int(inds.shape[0] if inds is not None else cols.shape[0])
+        row selections) with ``M`` (n x k), or dense ``cols`` (R x k x n), or
+        ``beh`` = (Yz (R, n, b) per-cell z-scored behaviour, U (cells*b, k),
+        rowcell (n,)) for the behaviour-PLS operator Yz_cell @ U_cell."""
+        R = int(inds.shape[0] if inds is not None else (cols.shape[0] if cols is not None else beh[0].shape[0]))
         out = torch.empty((R, k), dtype=torch.float64, device=self.device)
         if R == 0:
             return out
@@ -135,7 +142,10 @@ class ProjectionEngine:
             hi = min(R, lo + step)
             lay = self.layout(k, hi - lo)
             work, frag, need = self._scratch(lay, 0, "perm")
-            if cols is not None:
+            if beh is not None:
+                self._build_ops(lay, frag, beh=(self.dev(beh[0][lo:hi]), self.dev(beh[1]),
+                                                self.dev(beh[2], torch.int32)))
+            elif cols is not None:
                 self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
             else:
                 self._build_ops(lay, frag, inds=self.dev(inds[lo:hi], torch.int32), M=Md)
