@@ -194,10 +194,12 @@ struct Work {
 // wave x period group per workgroup
 int pick_split(const plsr_layout_t *lay, int64_t nvt) {
   if (lay->period == 0) {
-    // LV-major layout (K1br): splits per latent variable, for about twenty rounds
-    // of the 2048 resident waves (one wave per workgroup, grid.y = k * splits)
+    // LV-major layout (K1br): splits per latent variable, for about ten rounds of
+    // the 2048 resident waves (one wave per workgroup, grid.y = k * splits); measured
+    // at config 2: 5 / 10 / 20 / 30 rounds -> 2.71 / 2.69 / 2.72 / 2.81 ms, and fewer
+    // runs re-read X less often
     const int tpl = lay->Rp / 16;
-    const int64_t want = (20 * 2048 + nvt * lay->k - 1) / (nvt * lay->k);
+    const int64_t want = (10 * 2048 + nvt * lay->k - 1) / (nvt * lay->k);
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max(1, tpl / 4)));
   }
   const int groups = (lay->ntiles + WAVES * lay->period - 1) / (WAVES * lay->period);
