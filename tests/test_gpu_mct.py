@@ -180,3 +180,38 @@ def test_overlapped_tail_is_bit_identical():
         outs.append([t.cpu().numpy() for t in (res["S1"], res["S2"], res["ssq"], res["T"], ssq)])
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_register_resident_and_lds_fed_kernels_agree_at_full_size():
+    """Config-2 shape through both projection-kernel families: n = 60 takes the
+    register-resident kernels (K1r / K1br, LV-major batch order); the same data
+    padded with 8 zero rows (n = 68) takes the LDS-fed kernel (quad order).  The
+    zero rows change no statistic, so everything must agree to rounding."""
+    from plspy_amd import operators, resample
+    from plspy_amd.engine import ProjectionEngine
+    groups, nc, p = (10, 10), 3, 200_000
+    co = np.array([[g] * nc for g in groups])
+    rs = np.random.RandomState(5)
+    X = rs.randn(60, p)
+    W = operators.mean_centre_operator(co, 0)
+    Wm = operators.cell_mean_operator(co)
+    U, s, Vt = np.linalg.svd(W @ X, full_matrices=False)
+    M = W.T @ U
+    ref = Vt.T * s
+    np.random.seed(3)
+    pinds = resample.task_permutations(co, 37)
+    binds = resample.bootstraps(co, 41)
+    out = []
+    for pad in (0, 8):
+        Xp = np.vstack([X, np.zeros((pad, p))])
+        Mp = np.vstack([M, np.zeros((pad, M.shape[1]))])
+        pi = np.hstack([pinds, np.tile(np.arange(60, 60 + pad, dtype=np.int32), (len(pinds), 1))])
+        bi = np.hstack([binds, np.tile(np.arange(60, 60 + pad, dtype=np.int32), (len(binds), 1))])
+        eng = ProjectionEngine(Xp)
+        assert (eng.layout(6, 16).period == 0) == (pad == 0)
+        Xm = eng.apply_operator(np.hstack([Wm, np.zeros((Wm.shape[0], pad))]))
+        ssq = eng.perm_phase(6, inds=pi, M=Mp)
+        res = eng.boot_phase(6, inds=bi, M=Mp, ref=ref, Xm=Xm)
+        out.append([t.cpu().numpy() for t in (ssq, res["ssq"], res["T"], res["S1"], res["S2"])])
+    for name, a, b in zip(("perm ssq", "boot ssq", "T", "S1", "S2"), *out):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-9 * np.abs(b).max(), err_msg=name)
