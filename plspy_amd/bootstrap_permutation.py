@@ -417,16 +417,27 @@ class _ResampleTestPLS(ResampleTest):
             raise Exception(_DEGENERATE)                                               # :572
         return np.concatenate(got, axis=1) if multiblock else got[0]
 
-    def _finish_items(self, res, niter, ref):
-        """Exchange a sharded boot_items result and form std_errs / boot_ratios."""
-        eng = self._engine
-        (Zt, nsq), (S1, S2) = dist.exchange([res["Zt"], res["nsq"]], [res["S1"], res["S2"]], niter)
-        sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)                  # :695, :701
-        Z = np.transpose(Zt.cpu().numpy(), (0, 2, 1))                          # R x n x k  = X @ VS_b
-        norms = np.sqrt(nsq.cpu().numpy())                                     # R x k
+    @staticmethod
+    def _normalised_latents(zt, nsq):
+        """X @ normalize(VS_b) (:623) for a batch, from (X VS_b)^T (cnt, k, n) and the
+        squared column norms of VS_b (cnt, k): (cnt, n, k)."""
+        Z = np.transpose(zt, (0, 2, 1))
+        norms = np.sqrt(nsq)
         with np.errstate(divide="ignore", invalid="ignore"):
-            Zn = np.where(norms[:, None, :] != 0, Z / norms[:, None, :], 0.0)  # X @ normalize(VS_b)  (:623)
-        return sd.cpu().numpy(), ratio.cpu().numpy(), Zn
+            return np.where(norms[:, None, :] != 0, Z / norms[:, None, :], 0.0)
+
+    def _finish_items(self, res, per_resample, niter, ref):
+        """Exchange a sharded boot_items result (moment sums, and the per-resample
+        summaries the host formed batch by batch) and form std_errs / boot_ratios."""
+        eng = self._engine
+        _, nranks = dist.world()
+        if nranks > 1:
+            full, (S1, S2) = dist.exchange([eng.dev(a) for a in per_resample], [res["S1"], res["S2"]], niter)
+            per_resample = [t.cpu().numpy() for t in full]
+        else:
+            S1, S2 = res["S1"], res["S2"]
+        sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)                  # :695, :701
+        return sd.cpu().numpy(), ratio.cpu().numpy(), per_resample
 
     def _boot_rb(self, U, s, V, niter, lvcorrs_orig, CI):
         """bootstrap_permutation.py:467-766 for rb."""
@@ -453,11 +464,16 @@ class _ResampleTestPLS(ResampleTest):
                 ops[:, :, l:h] = np.swapaxes(Yz[:, l:h] @ U[c * b:(c + 1) * b], 1, 2)
             return ops
 
-        res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref)
-        std_errs, boot_ratios, Zn = self._finish_items(res, niter, ref)
-        # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
-        L = np.take_along_axis(Zn, inds[:, :, None].astype(np.int64), axis=1)
-        LVcorr = cf.corr_rows(L, cf.zscore_cells(Y[inds], bounds), bounds)
+        LVc = np.empty((hi - lo, (len(bounds) - 1) * b, k))
+
+        def on_batch(a, z, zt, nsq):
+            # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
+            Zn = self._normalised_latents(zt, nsq)
+            L = np.take_along_axis(Zn, mine[a:z][:, :, None].astype(np.int64), axis=1)
+            LVc[a:z] = cf.corr_rows(L, cf.zscore_cells(Y[mine[a:z]], bounds), bounds)
+
+        res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch)
+        std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z                                      # :723-724
         conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :725
@@ -515,18 +531,27 @@ class _ResampleTestPLS(ResampleTest):
                 scaled = U[None] / rownorm[:, :, None]
             return np.swapaxes(scaled, 1, 2) @ A                      # (r,j,k)(r,k,i) -> r,j,i
 
-        res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n)
-        std_errs, boot_ratios, Zn = self._finish_items(res, niter, ref)
-        # behaviour latents (:647-650): Xbscan_new @ V_hat = (X @ V_hat)[brows[bi]]
-        Lb = np.take_along_axis(Zn, brows[bi][:, :, None].astype(np.int64), axis=1)
-        LVcorr = cf.corr_rows(Lb, cf.zscore_cells(Yb[bi], bounds_b), bounds_b)
-        if self._C is None:
-            # task distribution (:654-656): cell means of smeanmat(X_new_T) @ V_hat
-            Lt = np.take_along_axis(Zn, ti[:, :, None].astype(np.int64), axis=1)
-            Tdistrib = cf.cell_means_rows(cf.smeanmat_rows(Lt, co, self._mctype), co)
-        else:
-            # cmb (:665-666): cell means of X @ normalize(crossblock.T), X itself
-            Tdistrib = cf.cell_means_rows(Zn, co)
+        cnt = hi - lo
+        LVc = np.empty((cnt, (len(bounds_b) - 1) * b, k))
+        Td = np.empty((cnt, co.size, k))
+        bi_m, ti_m = bi[lo:hi], ti[lo:hi]
+
+        def on_batch(a, z, zt, nsq):
+            Zn = self._normalised_latents(zt, nsq)
+            # behaviour latents (:647-650): Xbscan_new @ V_hat = (X @ V_hat)[brows[bi]]
+            Lb = np.take_along_axis(Zn, brows[bi_m[a:z]][:, :, None].astype(np.int64), axis=1)
+            LVc[a:z] = cf.corr_rows(Lb, cf.zscore_cells(Yb[bi_m[a:z]], bounds_b), bounds_b)
+            if self._C is None:
+                # task distribution (:654-656): cell means of smeanmat(X_new_T) @ V_hat
+                Lt = np.take_along_axis(Zn, ti_m[a:z][:, :, None].astype(np.int64), axis=1)
+                Td[a:z] = cf.cell_means_rows(cf.smeanmat_rows(Lt, co, self._mctype), co)
+            else:
+                # cmb (:665-666): cell means of X @ normalize(crossblock.T), X itself
+                Td[a:z] = cf.cell_means_rows(Zn, co)
+
+        res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n,
+                             on_batch=on_batch)
+        std_errs, boot_ratios, (LVcorr, Tdistrib) = self._finish_items(res, [LVc, Td], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z
         conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :723-725

@@ -51,6 +51,7 @@ class ProjectionEngine:
         self._lanes = {}
         self._tail = None
         self._h2d = None
+        self._d2h = None
 
     # -- helpers -----------------------------------------------------------
     def dev(self, a, dtype=torch.float64):
@@ -319,7 +320,8 @@ class ProjectionEngine:
             _stream()), "plsr_item_fused")
         return vst, (rowsq[:, :k] if want_rowsq else None)
 
-    def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None):
+    def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
+                   on_batch=None):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -329,6 +331,10 @@ class ProjectionEngine:
             given -- the (hi-lo, m) norms over all voxels of the rows
             raw_rows_fn(lo, hi) @ Z_b (the multiblock row normalisation);
         latent_rows: number of leading rows of X used for X @ VS_b (default n).
+        on_batch(lo, hi, Zt_host, nsq_host): optional consumer of every batch's
+            latent scores (NumPy, (hi-lo, k, n) and (hi-lo, k)); it is called one
+            batch late, while the device already works on the next batch, so the
+            host's per-resample post-processing hides behind the kernels.
         Returns dict(S1, S2 (p x k shifted moment sums), Zt (R, k, n) = (X VS_b)^T,
         nsq (R, k) = column norms^2 of VS_b)."""
         src = np.ascontiguousarray(src, dtype=np.int32)
@@ -342,6 +348,18 @@ class ProjectionEngine:
         ncell = len(cell_z)
         per_item = (2 * ncell + k + 4) * self.p * 8 + 2 * k * nz * 8
         step = int(max(1, min(R, (self.work_limit // 2) // per_item)))
+        pending = None
+
+        def deliver(job):
+            blo, bhi, ev = job
+            if self._d2h is None:
+                self._d2h = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._d2h):            # waits for that batch only, not for the stream's tail
+                self._d2h.wait_event(ev)
+                zt_h = Zt[blo:bhi].to("cpu")
+                nsq_h = nsq[blo:bhi].to("cpu")
+            on_batch(blo, bhi, zt_h.numpy(), nsq_h.numpy())
+
         for lo in range(0, R, step):
             hi = min(R, lo + step)
             cnt = hi - lo
@@ -365,6 +383,14 @@ class ProjectionEngine:
             _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
                                             k, _ptr(Zt[lo:hi]), _ptr(nsq2), _ptr(work2), need2,
                                             _stream()), "plsr_latent")
+            if on_batch is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                if pending is not None:
+                    deliver(pending)
+                pending = (lo, hi, ev)
+        if pending is not None:
+            deliver(pending)
         return {"S1": S1, "S2": S2, "Zt": Zt, "nsq": nsq, "R": R}
 
     def eigh(self, G, off, k):
