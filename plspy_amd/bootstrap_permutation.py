@@ -170,7 +170,8 @@ class _ResampleTestPLS(ResampleTest):
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
         if beh is not None:
-            ssq = eng.perm_phase(k, beh=(beh[0][lo:hi], beh[1], beh[2]))
+            make, count = beh[0], hi - lo          # beh[0](a, z): Yz of this rank's resamples a..z
+            ssq = eng.perm_phase(k, beh=(lambda a, z: make(lo + a, lo + z), beh[1], beh[2], count))
         elif cols is not None:
             ssq = eng.perm_phase(k, cols=cols[lo:hi])
         else:
@@ -260,9 +261,10 @@ class _ResampleTestPLS(ResampleTest):
         eng_z = ProjectionEngine(Xz, device=eng.device, work_limit=eng.work_limit)
         # operator column (b, j)[i] = sum_beh Yz_b[i, beh] * U[(cell(i), beh), j]
         # (the R x k x n operators are formed on the device from Yz and U)
-        Yz = cf.zscore_cells(Y[perms], bounds)                                 # R x n x b
+        # and the z-scored behaviour itself is made batch by batch, behind the kernels)
         rowcell = np.repeat(np.arange(len(bounds) - 1), np.diff(bounds)).astype(np.int32)
-        s_hat = np.sqrt(self._run_perm(eng_z, k, niter, beh=(Yz, U, rowcell)))
+        s_hat = np.sqrt(self._run_perm(
+            eng_z, k, niter, beh=(lambda a, z: cf.zscore_cells(Y[perms[a:z]], bounds), U, rowcell)))
         if self._C is None:
             s_hat[np.abs(s_hat) < threshold] = 0
         ratio, step = self._ratios(s_hat, s, np.copy(s), niter)

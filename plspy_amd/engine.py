@@ -133,19 +133,24 @@ class ProjectionEngine:
         row selections) with ``M`` (n x k), or dense ``cols`` (R x k x n), or
         ``beh`` = (Yz (R, n, b) per-cell z-scored behaviour, U (cells*b, k),
         rowcell (n,)) for the behaviour-PLS operator Yz_cell @ U_cell."""
-        R = int(inds.shape[0] if inds is not None else (cols.shape[0] if cols is not None else beh[0].shape[0]))
+        if beh is not None and callable(beh[0]):
+            R = int(beh[3])                      # (Yz_fn(lo, hi), U, rowcell, R): Yz made batch by batch
+        else:
+            R = int(inds.shape[0] if inds is not None else (cols.shape[0] if cols is not None else beh[0].shape[0]))
         out = torch.empty((R, k), dtype=torch.float64, device=self.device)
         if R == 0:
             return out
         step = self.batch_size(k, 0, R)
+        if beh is not None and callable(beh[0]):
+            step = min(step, 512)               # several batches, so that the host's Yz of batch i+1 hides behind batch i
         Md = self.dev(M)
         for lo in range(0, R, step):
             hi = min(R, lo + step)
             lay = self.layout(k, hi - lo)
             work, frag, need = self._scratch(lay, 0, "perm")
             if beh is not None:
-                self._build_ops(lay, frag, beh=(self.dev(beh[0][lo:hi]), self.dev(beh[1]),
-                                                self.dev(beh[2], torch.int32)))
+                Yz = beh[0](lo, hi) if callable(beh[0]) else beh[0][lo:hi]
+                self._build_ops(lay, frag, beh=(self.dev(Yz), self.dev(beh[1]), self.dev(beh[2], torch.int32)))
             elif cols is not None:
                 self._build_ops(lay, frag, cols=self.dev(cols[lo:hi]))
             else:
