@@ -177,10 +177,16 @@ struct FusedArgs {
   double *vst;                         // [items][k][ldv] VS^T, or null
   int64_t ldv;
   double *rowsq_part;                  // [nvt * VB][items][MC*16] or null
+  int32_t flat;                        // 1: four waves share the MC * items (tile, item) tasks evenly (MC = 3)
 };
 
 // TVX = voxels per workgroup (LDS tile n x TVX), NT = 16-voxel tiles per wave;
-// the workgroup has MC * VB waves, VB = TVX / (16 NT) voxel blocks
+// the workgroup has MC * VB waves, VB = TVX / (16 NT) voxel blocks.
+// Flat mode (MC = 3, NT = 4): three waves on four SIMDs leave a CU's matrix cores
+// a quarter idle, so FOUR waves split the 3 * items (tile, item) tasks evenly in
+// tile-major order: a wave then works on one tile for a run of items and possibly
+// on the next tile for another run ("segments"); a tile's moment sums come from
+// two waves and go to two partial slabs (zero-filled by the host, merged later).
 template <int NT, int TVX>
 __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -188,8 +194,7 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mc = wave % A.MC;
-  const int vb = wave / A.MC;
+  const int vb = A.flat ? 0 : wave / A.MC;
   const int col = lane & 15;
   const int g = lane >> 4;
   const int64_t v0 = (int64_t)blockIdx.x * TVX;
@@ -238,19 +243,55 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
       s2[nt][r] = 0.0;
     }
 
+  // this wave's segments: (tile of latent variables, run of items)
+  const int cnt = it_hi - it_lo;
+  int seg_mc[2], seg_a[2], seg_b[2], nseg = 1;
+  if (!A.flat) {
+    seg_mc[0] = wave % A.MC;
+    seg_a[0] = it_lo;
+    seg_b[0] = it_hi;
+  } else {
+    const int nw = blockDim.x >> 6;
+    const int U = A.MC * cnt;
+    const int u0 = (int)((int64_t)wave * U / nw), u1 = (int)((int64_t)(wave + 1) * U / nw);
+    const int m0 = u0 / cnt;
+    seg_mc[0] = m0;
+    seg_a[0] = it_lo + (u0 - m0 * cnt);
+    seg_b[0] = it_lo + min(cnt, u1 - m0 * cnt);
+    if (u1 > (m0 + 1) * cnt) {
+      nseg = 2;
+      seg_mc[1] = m0 + 1;
+      seg_a[1] = it_lo;
+      seg_b[1] = it_lo + (u1 - (m0 + 1) * cnt);
+    }
+    if (u0 >= u1) nseg = 0;
+  }
+
+  for (int sg = 0; sg < nseg; ++sg) {
+  const int mc = seg_mc[sg];
+  const int sa = seg_a[sg], sb = seg_b[sg];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[nt][r] = 0.0;
+      s2[nt][r] = 0.0;
+    }
+
   // Stream of k-steps over (item, cell, step): fragments and row offsets are
   // contiguous per wave, so the 4-deep register rings run on across cell and
   // item boundaries.  The k-loops hold no memory operation besides the rings
   // (the scale / shift of a cell are prefetched one cell ahead, between loops).
   const double *fp = A.frag + ((size_t)mc * A.items * nkp + (size_t)it_lo * nkp) * 64 + lane;
   const int32_t *rp = tbl + g;           // LDS: byte offset of the row of (step, lane group)
+  int64_t pos = (int64_t)(sa - it_lo) * nkp;    // stream position of the current cell's first step
   double ra[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) ra[u] = fp[(size_t)u * 64];
+  for (int u = 0; u < 4; ++u) ra[u] = fp[(size_t)(pos + u) * 64];
   double bn[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + rp[0] + nt * 128);
-  int ro1 = rp[4];                       // rows of the next step
+  for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + rp[pos * 4] + nt * 128);
+  int ro1 = rp[(pos + 1) * 4];           // rows of the next step
 
   // Unconditional loads (clamped addresses): a select on the loaded value would
   // make the prefetch wait for its own data.  Lanes past p read voxel p-1 and
@@ -266,15 +307,14 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   };
 
   double sc[NT], sh[NT], scn[NT], shn[NT];
-  load_cell(it_lo, 0, scn, shn);
+  load_cell(sa, 0, scn, shn);
 
   f64x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-  int64_t pos = 0;                       // stream position of the current cell's first step
-  int phase = 0;                         // ring slot of that step
-  for (int item = it_lo; item < it_hi; ++item) {
+  int phase = 0;                         // ring slot of the current cell's first step
+  for (int item = sa; item < sb; ++item) {
     for (int c = 0; c < ncell; ++c) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -367,8 +407,10 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   }
 
   if (moments) {
-    double *o1 = A.S1 + (int64_t)blockIdx.y * A.p * A.k;
-    double *o2 = A.S2 + (int64_t)blockIdx.y * A.p * A.k;
+    // flat mode: the wave that starts a tile's items writes slab 0, the one that ends them slab 1
+    const int slab = A.flat ? 2 * blockIdx.y + (sa == it_lo ? 0 : 1) : blockIdx.y;
+    double *o1 = A.S1 + (int64_t)slab * A.p * A.k;
+    double *o2 = A.S2 + (int64_t)slab * A.p * A.k;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -380,6 +422,7 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
         }
       }
   }
+  }   // segments
 }
 
 // S1 += sum_b (x_b - ref),  S2 += sum_b (x_b - ref)^2  from the plain partial

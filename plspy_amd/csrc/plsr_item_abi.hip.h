@@ -122,7 +122,7 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
 namespace {
 struct FusedPlan {
   FusedCells cells;
-  int MC, NT, TVX, VB, waves, nsplit, nchunk;
+  int MC, NT, TVX, VB, waves, nsplit, nchunk, flat, nslabm;
   int64_t nvt, nslab;
   size_t lds;
   // workspace carve (byte offsets)
@@ -145,6 +145,8 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   pl.NT = pl.MC >= 3 ? 4 : pl.MC;
   pl.VB = pl.TVX / (16 * pl.NT);
   pl.waves = pl.MC * pl.VB;
+  pl.flat = pl.MC == 3 ? 1 : 0;        // four waves share three tiles' worth of (tile, item) tasks
+  if (pl.flat) pl.waves = 4;
   const size_t lds_x = (size_t)n * pl.TVX * sizeof(double);
   if ((size_t)n * TV * sizeof(double) > 160 * 1024) return false;      // the statistics kernel's tile
   pl.cells.ncell = ncell;
@@ -186,7 +188,8 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   pl.o_rowoff = take(((size_t)items * steps + 8) * 4 * sizeof(int32_t));
   pl.o_sc = take((size_t)items * ncell * p * sizeof(double));
   pl.o_sh = take((size_t)items * ncell * p * sizeof(double));
-  pl.o_mom = take(moments ? (size_t)2 * pl.nsplit * p * k * sizeof(double) : 0);
+  pl.nslabm = pl.flat ? 2 * pl.nsplit : pl.nsplit;
+  pl.o_mom = take(moments ? (size_t)2 * pl.nslabm * p * k * sizeof(double) : 0);
   pl.o_sq = take(rowsq ? (size_t)pl.nslab * E * sizeof(double) : 0);
   pl.o_sq2 = take(rowsq ? (size_t)pl.nchunk * E * sizeof(double) : 0);
   pl.bytes = off;
@@ -278,7 +281,10 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   a.sh = sa.sh;
   a.ref = d_ref;
   a.S1 = d_S1 ? (double *)(w + pl.o_mom) : nullptr;
-  a.S2 = d_S1 ? a.S1 + (size_t)pl.nsplit * p * k : nullptr;
+  a.S2 = d_S1 ? a.S1 + (size_t)pl.nslabm * p * k : nullptr;
+  a.flat = pl.flat;
+  if (d_S1 && pl.flat)   // a (tile, part) pair without items writes nothing
+    (void)hipMemsetAsync(a.S1, 0, (size_t)2 * pl.nslabm * p * k * sizeof(double), st);
   a.vst = d_vst;
   a.ldv = ldv;
   a.rowsq_part = d_rowsq ? (double *)(w + pl.o_sq) : nullptr;
@@ -291,7 +297,7 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
     const int64_t cnt = p * k;
     dim3 g((unsigned)((cnt + 255) / 256));
     hipLaunchKernelGGL(moment_unshift_kernel, g, dim3(256), 0, st, d_S1, d_S2, (const double *)a.S1,
-                       (const double *)a.S2, d_ref, cnt, pl.nsplit, (double)items);
+                       (const double *)a.S2, d_ref, cnt, pl.nslabm, (double)items);
   }
   if (d_rowsq) {
     const int64_t E = (int64_t)items * pl.MC * 16;
