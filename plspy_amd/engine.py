@@ -37,7 +37,7 @@ class ProjectionEngine:
     work_limit bounds the scratch a single batch may use; larger phases are
     cut into batches of resamples (each batch is one kernel launch)."""
 
-    def __init__(self, X, device=None, work_limit=6 << 30):
+    def __init__(self, X, device=None, work_limit=24 << 30):
         if not torch.cuda.is_available():
             raise RuntimeError("plspy_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.lib = _lib.load()
