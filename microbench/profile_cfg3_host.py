@@ -22,7 +22,7 @@ V = rs.randn(p, k)
 np.random.seed(1)
 import time
 def run():
-    return ResampleTest._create("rb", X, Y, U, s.copy(), V, co, 0, nperm=0, nboot=310,
+    return ResampleTest._create("rb", X, Y, U, s.copy(), V, co, 0, nperm=0, nboot=2000,
                                 lvcorrs_orig=np.zeros((k, k)), engine=eng)
 run()
 pr = cProfile.Profile()

@@ -470,9 +470,9 @@ class _ResampleTestPLS(ResampleTest):
 
         def on_batch(a, z, zt, nsq):
             # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
-            Zn = self._normalised_latents(zt, nsq)
-            L = np.take_along_axis(Zn, mine[a:z][:, :, None].astype(np.int64), axis=1)
-            LVc[a:z] = cf.corr_rows(L, cf.zscore_cells(Y[mine[a:z]], bounds), bounds)
+            # (no transposes, and no division by the column norms: see lvcorr_from_latents)
+            Lt = np.take_along_axis(zt, mine[a:z][:, None, :].astype(np.int64), axis=2)
+            LVc[a:z] = cf.lvcorr_from_latents(Lt, cf.zscore_cells(Y[mine[a:z]], bounds), bounds)
 
         res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch)
         std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)

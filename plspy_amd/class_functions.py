@@ -69,6 +69,26 @@ def zscore_cells(M, bounds):
     return out
 
 
+def lvcorr_from_latents(Lt, Yz, bounds):
+    """Bootstrap LVcorr for a batch: Lt (cnt, k, n) = the resampled rows of
+    (X @ V_hat)^T, Yz (cnt, n, b) per-cell z-scored behaviour -> (cnt, cells*b, k),
+    i.e. corr_rows(Lt^T, Yz) without the transposes.  The per-cell z-score is
+    scale invariant, so the column normalisation of V_hat (:623) may be skipped:
+    a zero column gives a constant (zero) latent, which z-scores to 0 either way."""
+    out = []
+    eps = np.finfo(float).eps
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        blk = Lt[:, :, lo:hi]
+        mu = blk.mean(axis=-1, keepdims=True)
+        d = blk - mu
+        sd = np.sqrt(np.mean(d * d, axis=-1, keepdims=True))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            z = d / (sd * np.sqrt(hi - lo))
+        z[np.broadcast_to(~(sd > eps * np.abs(mu)), z.shape)] = 0.0
+        out.append(np.swapaxes(z @ Yz[:, lo:hi], 1, 2))          # (cnt, k, nc)(cnt, nc, b) -> cnt, b, k
+    return np.concatenate(out, axis=1)
+
+
 def compute_corr_small(L, Y, cond_order):
     """_compute_corr (class_functions.py:185-247) for a small left matrix
     (latent scores n x k): stacked per-cell Yz.T @ Lz, (cells*b) x k."""
