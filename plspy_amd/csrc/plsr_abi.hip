@@ -459,6 +459,7 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   if (w.bytes > work_bytes) return PLSR_EWORKSPACE;
   a.norm_part = w.norm_part;
   a.T_part = w.T_part;
+  a.sink = w.sink;
   a.ref = d_ref;
   a.Xm = k2 > 0 ? d_Xm : nullptr;
   a.ldxm = ldxm;

@@ -349,21 +349,27 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
       }
       nsq += __shfl_xor(nsq, 16);
       nsq += __shfl_xor(nsq, 32);
-#if PLSR_ABLATE & 32
-      if (nsq == 77.0)
-#else
-      if (g == 0)
-#endif
-        A.norm_part[vt * C + (int64_t)t * 16 + col] = nsq;
-      if (BOOT && A.k2 > (PLSR_ABLATE & 32 ? 1000 : 0)) {
+#if !(PLSR_ABLATE & 32)
+      {
+        // unconditional store (idle lanes write a sink): a store under a branch makes
+        // the compiler wait for vmcnt(0) where the fragment ring is used next
+        double *dst = g == 0 ? A.norm_part + (vt * C + (int64_t)t * 16 + col) : A.sink + lane;
+        *dst = nsq;
+      }
+      if (BOOT) {
         // D_b[i][j] sits at lane 16 i + 4 b + j: batch column c = 4 b + i, cell = 4 h + j
         const int c = 4 * ((lane & 15) >> 2) + (lane >> 4);
+        double *tp = A.T_part + (vt * C + (int64_t)t * 16 + c) * A.k2;     // never dereferenced when k2 = 0
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           const int cell = 4 * h + (lane & 3);
-          if (h < nh && cell < A.k2) A.T_part[(vt * C + (int64_t)t * 16 + c) * A.k2 + cell] = accT[h];
+          if (h < nh) {
+            double *dst = cell < A.k2 ? tp + cell : A.sink + lane;
+            *dst = accT[h];
+          }
         }
       }
+#endif
     }
   }
 
