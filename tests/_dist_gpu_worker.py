@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a two-rank (gloo) run of the real
+resampling classes on the GPU; rank 0 writes what it ends with."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def problems():
+    rs = np.random.RandomState(4)
+    co = np.array([[5, 5], [4, 4]])
+    n = int(co.sum())
+    X = rs.randn(n, 700)
+    Y = rs.randn(n, 3)
+    return co, X, Y
+
+
+def run(single):
+    from oracle import plspy_oracle as orc
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    co, X, Y = problems()
+    out = {}
+    obs = orc.observed("mct", X, co, mctype=0)
+    np.random.seed(11)
+    rt = ResampleTest._create("mct", X, None, obs["U"], obs["s"].copy(), obs["V"], co, 0, nperm=9, nboot=11,
+                              Tvsc_orig=obs["Tvsc_orig"])
+    out.update(mct_perm=rt.perm_debug_dict["s_list"], mct_std=rt.std_errs, mct_ratio=rt.boot_ratios,
+               mct_T=rt.boot_debug_dict["Tdistrib"])
+    obs = orc.observed("rb", X, co, Y=Y)
+    np.random.seed(12)
+    rt = ResampleTest._create("rb", X, Y, obs["U"], obs["s"].copy(), obs["V"], co, 0, nperm=7, nboot=10,
+                              lvcorrs_orig=obs["lvcorrs"])
+    out.update(rb_perm=rt.perm_debug_dict["s_list"], rb_std=rt.std_errs, rb_lvcorr=rt.LVcorr)
+    return out
+
+
+if __name__ == "__main__":
+    import torch
+    import torch.distributed as td
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo")
+    res = run(False)
+    if td.get_rank() == 0:
+        np.savez(sys.argv[1], **res)
+    td.barrier()
+    td.destroy_process_group()
