@@ -34,6 +34,16 @@ def run(single):
     rt = ResampleTest._create("rb", X, Y, obs["U"], obs["s"].copy(), obs["V"], co, 0, nperm=7, nboot=10,
                               lvcorrs_orig=obs["lvcorrs"])
     out.update(rb_perm=rt.perm_debug_dict["s_list"], rb_std=rt.std_errs, rb_lvcorr=rt.LVcorr)
+    bscan = [0, 1]
+    obs = orc.observed("mb", X, co, Y=Y, mctype=0, bscan=bscan)
+    np.random.seed(13)
+    rt = ResampleTest._create(
+        "mb", X, Y, obs["U"], obs["s"].copy(), obs["V"], co, 0, nperm=6, nboot=9, bscan=bscan,
+        Xbscan=obs["Xbscan"], Ybscan=obs["Ybscan"],
+        lvcorrs_orig=orc.compute_corr(obs["Xbscan"] @ obs["V"], obs["Ybscan"], co[:, bscan]),
+        Tvsc_orig=orc.group_condition_means(X @ orc.normalize(obs["V"]), co))
+    out.update(mb_perm=rt.perm_debug_dict["s_list"], mb_std=rt.std_errs, mb_lvcorr=rt.LVcorr,
+               mb_T=rt.boot_debug_dict["Tdistrib"])
     return out
 
 
