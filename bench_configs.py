@@ -6,6 +6,7 @@
   --config 4   mb  same data, bscan=[1,2], split-half (splits/s)
   --config 5   mct X=(240x500000) groups [20]x4 x 3, perm + boot
   --config 2   mct X=(60x200000) through PLS() end to end (host draws, observed SVD included)
+  --config 6   mb  config 4's data, permutation + bootstrap (not in BASELINE.json)
 
 ``--count`` sets the number of resamples per loop (BASELINE's full counts are
 2000/2000, 1000 splits, 5000/5000); rates are per second of the resampling
@@ -88,6 +89,21 @@ def main():
         _, t_sh = timed(lambda: sh.split_half("mb", X, Y, co, S, lv=2, CI=0.95, **kw))
         out.update(workload=f"mb X=120x200000 Y=120x8 bscan=[1,2] (k=38), {S} splits (tt + sh, real + null)",
                    seconds_test_train=t_tt, seconds_split_half=t_sh, splits_per_s=S / (t_tt + t_sh))
+    elif args.config == 6:
+        # not a BASELINE configuration: the multiblock permutation / bootstrap
+        # on config 4's data, which BASELINE only exercises through split-half
+        R = args.count or 500
+        X, Y = data(120, 200_000, 8)
+        mk = lambda nperm, nboot: plspy_amd.PLS(X, [20, 20], 3, Y=Y, num_perm=nperm, num_boot=nboot,
+                                                pls_method="mb", bscan=[1, 2])
+        _, t_obs = timed(lambda: mk(0, 0))
+        _, t_obs = timed(lambda: mk(0, 0))                       # warm
+        _, t_p = timed(lambda: mk(R, 0))
+        _, t_b = timed(lambda: mk(0, R))
+        t_perm, t_boot = t_p - t_obs, t_b - t_obs                # the observed decomposition is in both
+        out.update(workload=f"mb X=120x200000 Y=120x8 bscan=[1,2] (k=38), {R} perm + {R} boot",
+                   seconds_observed=t_obs, seconds_perm=t_perm, seconds_boot=t_boot, perms_per_s=R / t_perm,
+                   boots_per_s=R / t_boot)
     print(json.dumps(out))
 
 

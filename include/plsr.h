@@ -226,6 +226,18 @@ int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     size_t work_bytes, void *stream);
 
 /*
+ * Multiblock operator rows for plsr_item_fused, formed on the device from the
+ * un-normalised rows and the squared row norms plsr_item_fused returned for them
+ * (two-phase row normalisation, class_functions.py:503-505, then `@ U`, :620):
+ *   d_out[b][j][i] = sum_r d_U[r][j] / sqrt(d_rowsq[b][r]) * d_raw[b][r][i]
+ * (a row of norm 0 contributes 0).  d_raw [items][kr][nz], d_rowsq [items][rowsq_stride],
+ * d_U [kr][k], d_out [items][k][nz].
+ */
+int plsr_scale_project_rows(const double *d_raw, const double *d_rowsq, int64_t rowsq_stride,
+                            const double *d_U, int32_t items, int32_t kr, int32_t nz, int32_t k,
+                            double *d_out, void *stream);
+
+/*
  * plsr_gram_batch with the gather / z-score of K4f fused in (split-half of
  * behaviour / multiblock PLS, split_half_resampling.py:136-398): item b's matrix
  * is X[d_src[b]] z-scored within the cells, never stored; G_b = (rows_b Z_b)(rows_b Z_b)^T.

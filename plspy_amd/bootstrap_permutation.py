@@ -552,7 +552,7 @@ class _ResampleTestPLS(ResampleTest):
                 Td[a:z] = cf.cell_means_rows(Zn, co)
 
         res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n,
-                             on_batch=on_batch)
+                             on_batch=on_batch, project_on=U)
         std_errs, boot_ratios, (LVcorr, Tdistrib) = self._finish_items(res, [LVc, Td], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z

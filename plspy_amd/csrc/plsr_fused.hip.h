@@ -425,6 +425,30 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   }   // segments
 }
 
+// Multiblock operator rows on the device (class_functions.py:503-505 + :620):
+//   out[b][j][i] = sum_r U[r][j] / sqrt(rowsq[b][r]) * raw[b][r][i]
+// i.e. the un-normalised multiblock rows of resample b, each scaled by the inverse of
+// its norm over all voxels (a zero row stays zero, as _normalize does) and projected on
+// U -- formed where the norms already are, so the host never waits for them.
+__global__ __launch_bounds__(256) void scale_project_rows_kernel(const double *raw, const double *rowsq,
+                                                                int64_t rowsq_stride, const double *U, int items,
+                                                                int kr, int nz, int k, double *out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)items * k * nz) return;
+  const int i = (int)(e % nz);
+  const int j = (int)((e / nz) % k);
+  const int b = (int)(e / ((int64_t)nz * k));
+  const double *rb = raw + (int64_t)b * kr * nz + i;
+  const double *qb = rowsq + (int64_t)b * rowsq_stride;
+  double a = 0.0;
+  for (int r = 0; r < kr; ++r) {
+    const double q = qb[r];
+    const double inv = q > 0.0 ? 1.0 / sqrt(q) : 0.0;
+    a = fma(U[(int64_t)r * k + j] * inv, rb[(int64_t)r * nz], a);
+  }
+  out[e] = a;
+}
+
 // S1 += sum_b (x_b - ref),  S2 += sum_b (x_b - ref)^2  from the plain partial
 // sums  P1 = sum x_b,  P2 = sum x_b^2  of `items` resamples (fixed split order).
 // The expansion loses eps * mean^2 / var relative accuracy, the same as the

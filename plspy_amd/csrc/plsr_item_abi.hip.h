@@ -432,3 +432,14 @@ extern "C" int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_
                      (const double *)d_work, d_G, E, g.nchunk, g.nchunk);
   return launch_ok();
 }
+
+extern "C" int plsr_scale_project_rows(const double *d_raw, const double *d_rowsq, int64_t rowsq_stride,
+                                       const double *d_U, int32_t items, int32_t kr, int32_t nz, int32_t k,
+                                       double *d_out, void *stream) {
+  if (!d_raw || !d_rowsq || !d_U || !d_out || items <= 0 || kr <= 0 || nz <= 0 || k <= 0 || rowsq_stride < kr)
+    return PLSR_EINVAL;
+  const int64_t total = (int64_t)items * k * nz;
+  hipLaunchKernelGGL(scale_project_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_raw, d_rowsq, rowsq_stride, d_U, items, kr, nz, k, d_out);
+  return launch_ok();
+}

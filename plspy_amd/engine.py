@@ -326,7 +326,7 @@ class ProjectionEngine:
         return vst, (rowsq[:, :k] if want_rowsq else None)
 
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
-                   on_batch=None):
+                   on_batch=None, project_on=None):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -335,6 +335,9 @@ class ProjectionEngine:
             VS_b = ops_b @ Z_b; rownorm is None, or -- when raw_rows_fn is
             given -- the (hi-lo, m) norms over all voxels of the rows
             raw_rows_fn(lo, hi) @ Z_b (the multiblock row normalisation);
+        project_on: (m, k) matrix U.  With raw_rows_fn, the operator rows are then
+            formed on the device, ops_b = U^T diag(1 / rownorm_b) raw_b, and ops_fn
+            is not called -- the host never waits for the norms;
         latent_rows: number of leading rows of X used for X @ VS_b (default n).
         on_batch(lo, hi, Zt_host, nsq_host): optional consumer of every batch's
             latent scores (NumPy, (hi-lo, k, n) and (hi-lo, k)); it is called one
@@ -374,9 +377,19 @@ class ProjectionEngine:
                 # two-phase row normalisation of the multiblock (class_functions.py:503-505):
                 # norms over all voxels of the un-normalised rows, K4f in norms-only mode
                 raw = np.ascontiguousarray(raw_rows_fn(lo, hi), dtype=np.float64)
-                _, rsq = self.item_fused(d_src, cell_lo, cell_z, raw, want_rowsq=True)
-                rownorm = np.sqrt(rsq.cpu().numpy())
-            ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
+                d_raw = self.dev(raw)
+                _, rsq = self.item_fused(d_src, cell_lo, cell_z, d_raw, want_rowsq=True)
+                if project_on is None:
+                    rownorm = np.sqrt(rsq.cpu().numpy())
+            if raw_rows_fn is not None and project_on is not None:
+                d_U = self.dev(project_on)
+                m = int(d_raw.shape[1])
+                ops = torch.empty((cnt, k, nz), dtype=torch.float64, device=self.device)
+                _lib.check(self.lib.plsr_scale_project_rows(_ptr(d_raw), _ptr(rsq), rsq.stride(0), _ptr(d_U), cnt,
+                                                            m, nz, k, _ptr(ops), _stream()),
+                           "plsr_scale_project_rows")
+            else:
+                ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
             vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
                                        want_rowsq=True)
             nsq[lo:hi] = rsq
