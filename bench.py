@@ -126,9 +126,18 @@ def main():
         # permutation kernel (the projection kernels themselves stay serialised)
         res = eng.boot_phase(k, inds=d_boot, M=Md, ref=ref, Xm=Xm, overlap_tail=True)
         ssq = eng.perm_phase(k, inds=d_perm, M=Md)
-        eng.join()
-        (ssq_all,), _ = dist.exchange([ssq], [], RP)
-        (bs, T), (S1, S2) = dist.exchange([res["ssq"], res["T"]], [res["S1"], res["S2"]], RB)
+        if world > 1:
+            # the bootstrap's collectives are enqueued behind its reduction tail, on the
+            # tail stream: the moment sums cross xGMI while the permutation kernel runs
+            with eng.tail_stream():
+                (bs, T), (S1, S2) = dist.exchange([res["ssq"], res["T"]], [res["S1"], res["S2"]], RB)
+            eng.join()
+            for t in (bs, T, S1, S2):
+                t.record_stream(torch.cuda.current_stream())
+            (ssq_all,), _ = dist.exchange([ssq], [], RP)
+        else:
+            eng.join()
+            ssq_all, bs, T, S1, S2 = ssq, res["ssq"], res["T"], res["S1"], res["S2"]
         sd, ratio = eng.boot_finalize(S1, S2, RB, num=ref)
         return ssq_all, bs, T, sd, ratio
 
@@ -218,7 +227,7 @@ def main():
                                 "algorithmic_equivalent_tflops": f_perm * NPERM / (pm * 1e-3) / 1e12},
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU baseline is an N = 1 figure (rank 0's host cores)
             from oracle import plspy_oracle as orc
             obs = {"U": U, "s": s, "V": V, "Tvsc_orig": Wm @ (X @ V)}
             line["cpu_baseline"] = cpu_baseline(X, co, obs, args.cpu_iters)

@@ -113,6 +113,14 @@ class ProjectionEngine:
         if self._tail is not None:
             torch.cuda.current_stream().wait_stream(self._tail)
 
+    def tail_stream(self):
+        """Context in which torch work (the collectives of dist.exchange) is enqueued
+        on the tail stream, i.e. behind the reductions of an overlapped bootstrap
+        phase and beside whatever the main stream runs next."""
+        if self._tail is None:
+            self._tail = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(self._tail)
+
     def _build_ops(self, lay, frag, inds=None, M=None, cols=None, beh=None):
         if beh is not None:
             Yz, U, rowcell = beh
