@@ -196,6 +196,18 @@ int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const doub
                 size_t work_bytes, void *stream);
 
 /*
+ * ---- K0: a handful of operator rows applied to X ------------------------------
+ * d_out (m x p, row stride ldo) = d_rows (m x n, row-major) @ X.  The observed
+ * blocks of a PLS() call: _mean_centre / cell means as the operator W
+ * (class_functions.py:7-95, pls_classes.py:211-266), the behaviour correlation
+ * block on the z-scored X (:185-247), the multiblock (:454-516), contrast
+ * projections (:126-162) and the back-projection V = M^T U / s of _run_pls
+ * (:98-123).  HBM-bound (X is read once per 16 output rows).  n <= 512.
+ */
+int plsr_apply_rows(const double *d_X, int64_t ldx, int64_t p, int32_t n, const double *d_rows,
+                    int32_t m, double *d_out, int64_t ldo, void *stream);
+
+/*
  * ---- K4f: fused gather / z-score / projection ---------------------------------
  * Every bootstrap sample of behaviour / multiblock PLS z-scores its own
  * resampled rows (class_functions.py:221-238 on X[inds]), so each resample

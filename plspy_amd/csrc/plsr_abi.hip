@@ -718,6 +718,15 @@ extern "C" int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, con
   return check_launch();
 }
 
+extern "C" int plsr_apply_rows(const double *d_X, int64_t ldx, int64_t p, int32_t n, const double *d_rows,
+                               int32_t m, double *d_out, int64_t ldo, void *stream) {
+  if (!d_X || !d_rows || !d_out || n <= 0 || m <= 0 || p <= 0 || ldx < p || ldo < p) return PLSR_EINVAL;
+  if ((size_t)n * 16 * sizeof(double) > 64 * 1024) return PLSR_EUNSUPPORTED;       // n <= 512
+  hipLaunchKernelGGL(rows_apply_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)((m + 15) / 16)), dim3(256),
+                     (size_t)n * 16 * sizeof(double), (hipStream_t)stream, d_X, ldx, p, n, d_rows, m, d_out, ldo);
+  return check_launch();
+}
+
 // K4 / K5 entry points (same translation unit: the shared kernels in
 // plsr_project.hip.h are defined once)
 #include "plsr_item_abi.hip.h"

@@ -22,6 +22,22 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device, name):
+    """The process-wide copy / tail stream `name` of a device.  Shared by every engine:
+    torch's caching allocator keeps one pool per stream, so engines that each made
+    their own streams (one PLS() call makes several engines) could never reuse the
+    blocks of the previous call and paid a fresh device allocation (hipMalloc and the
+    first touch of the new segment: 5-25 ms on this system) per call."""
+    key = (str(device), name)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _Lane:
     """Scratch of one phase kind (the permutation and bootstrap phases keep
     separate scratch so that one's reductions may overlap the other's kernel)."""
@@ -67,7 +83,7 @@ class ProjectionEngine:
             if src.dtype != dtype:
                 src = src.to(dtype)
             if self._h2d is None:
-                self._h2d = torch.cuda.Stream(device=self.device)
+                self._h2d = _side_stream(self.device, "h2d")
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(self._h2d):
                 t = src.to(self.device)
@@ -118,7 +134,7 @@ class ProjectionEngine:
         on the tail stream, i.e. behind the reductions of an overlapped bootstrap
         phase and beside whatever the main stream runs next."""
         if self._tail is None:
-            self._tail = torch.cuda.Stream(device=self.device)
+            self._tail = _side_stream(self.device, "tail")
         return torch.cuda.stream(self._tail)
 
     def _build_ops(self, lay, frag, inds=None, M=None, cols=None, beh=None):
@@ -189,7 +205,7 @@ class ProjectionEngine:
             step = self.batch_size(k, k2, R)
             Md = self.dev(M)
             if overlap_tail and self._tail is None:
-                self._tail = torch.cuda.Stream(device=self.device)
+                self._tail = _side_stream(self.device, "tail")
             if not overlap_tail:
                 self.join()          # an earlier overlapped tail may still read the bootstrap scratch
             tail = ctypes.c_void_p(self._tail.cuda_stream) if overlap_tail else ctypes.c_void_p(0)
@@ -224,16 +240,16 @@ class ProjectionEngine:
         return sd, ratio
 
     def apply_operator(self, rows):
-        """(m x n) operator rows -> (m x p) = rows @ X, through the projection
-        kernel (used for the observed cell means / centred block)."""
-        rows = np.asarray(rows, dtype=float)
-        m = rows.shape[0]
-        out = []
-        for lo in range(0, m, 16):
-            blk = rows[lo:lo + 16]
-            res = self.boot_phase(blk.shape[0], cols=blk[None, :, :], dump=True)
-            out.append(res["vs"][0].T)
-        return torch.cat(out, dim=0)
+        """(m x n) operator rows -> (m x p) = rows @ X on the device (K0; the observed
+        cell means / centred block / correlation block / back-projection)."""
+        d_rows = self.dev(np.ascontiguousarray(rows, dtype=np.float64))
+        m, n = d_rows.shape
+        if n != self.n:
+            raise ValueError(f"operator rows have {n} columns, X has {self.n} rows")
+        out = torch.empty((m, self.p), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.plsr_apply_rows(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_rows), m,
+                                            _ptr(out), self.p, _stream()), "plsr_apply_rows")
+        return out
 
     # -- K2: Gram / thin SVD -------------------------------------------------
     def gram_phase(self, rows, gather=None):
@@ -369,7 +385,7 @@ class ProjectionEngine:
         def deliver(job):
             blo, bhi, ev = job
             if self._d2h is None:
-                self._d2h = torch.cuda.Stream(device=self.device)
+                self._d2h = _side_stream(self.device, "d2h")
             with torch.cuda.stream(self._d2h):            # waits for that batch only, not for the stream's tail
                 self._d2h.wait_event(ev)
                 zt_h = Zt[blo:bhi].to("cpu")

@@ -143,3 +143,19 @@ def test_projection_phases_random_shapes():
             T = np.einsum("bvk,cv->bkc", VS, Xm)
             np.testing.assert_allclose(res["T"].cpu().numpy(), T, rtol=1e-9, atol=1e-10 * (np.abs(T).max() + 1),
                                        err_msg=tag)
+
+
+def test_apply_rows_random_shapes():
+    """K0 (plsr_apply_rows: the observed blocks, rows @ X) against NumPy: row counts on both
+    sides of the 16-row slice, voxel counts that do not fill a workgroup, n not a multiple of 4."""
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(99)
+    for n, p, m in [(7, 1, 1), (60, 255, 6), (61, 257, 16), (120, 1000, 17), (240, 513, 40), (13, 64, 33)]:
+        X = rs.randn(n, p)
+        rows = rs.randn(m, n)
+        eng = ProjectionEngine(X)
+        got = eng.apply_operator(rows).cpu().numpy()
+        want = rows @ X
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max(), err_msg=f"{n} {p} {m}")
+    with pytest.raises(ValueError):
+        eng.apply_operator(np.zeros((2, 5)))
