@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=40, help="oracle iterations per loop for cpu_baseline")
+    ap.add_argument("--cpu-iters", type=int, default=120, help="oracle iterations per loop for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
