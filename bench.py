@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=120, help="oracle iterations per loop for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps, rank 0 recomputes the whole job alone and compares it with "
+                         "what the ranks exchanged (test switch; outside the timed region)")
     return ap.parse_args()
 
 
@@ -161,6 +164,20 @@ def main():
     nt = lib.plsr_timing_collect(ms, kind, 4096)
     boot_ms = [ms[i] for i in range(nt) if kind[i] == 1]
     perm_ms = [ms[i] for i in range(nt) if kind[i] == 0]
+
+    if args.verify and rank == 0:
+        # the whole job (all ranks' resamples) on this rank alone, without any exchange
+        full_b = eng.boot_phase(k, inds=eng.dev(boot_inds, torch.int32), M=Md, ref=ref, Xm=Xm)
+        full_p = eng.perm_phase(k, inds=eng.dev(perm_inds, torch.int32), M=Md)
+        sd1, ratio1 = eng.boot_finalize(full_b["S1"], full_b["S2"], RB, num=ref)
+        torch.cuda.synchronize()
+        for name, got, want in (("perm ssq", out[0], full_p), ("boot ssq", out[1], full_b["ssq"]),
+                                ("T", out[2], full_b["T"]), ("std_errs", out[3], sd1), ("boot_ratios", out[4], ratio1)):
+            g, w = got.cpu().numpy(), want.cpu().numpy()
+            assert g.shape == w.shape, (name, g.shape, w.shape)
+            err = float(np.max(np.abs(g - w)) / max(np.max(np.abs(w)), 1e-300))
+            assert err < 1e-11, f"--verify: {name} differs from the single-rank result by {err:.2e} (relative)"
+        print(f"[verify] {world} rank(s): exchanged results match the single-rank recomputation", file=sys.stderr)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64,
                         device=eng.device if (world == 1 or td.get_backend() == "nccl") else "cpu")

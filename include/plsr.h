@@ -186,7 +186,8 @@ int plsr_gather_zscore(const double *d_X, int64_t ldx, int64_t p, const int32_t 
  * ---- K5: latent scores of the behaviour / multiblock bootstrap -----------------
  * plsr_latent:  d_Zt[b][j][i] = sum_v VS_b[j][v] X[i][v]   (X @ VS_b,
  *     bootstrap_permutation.py:638/:647/:655 before the column normalisation)
- *     d_nsq[b][j]   = sum_v VS_b[j][v]^2                       (:623 norms)
+ *     d_nsq[b][j]   = sum_v VS_b[j][v]^2                       (:623 norms; d_nsq may be
+ *     null -- plsr_item_fused already returns these norms as its row norms)
  * from d_vst[b][j][v] = VS_b[j][v] (k x ldv per item, written by plsr_item_fused).
  * k <= 64, n <= 256.
  */

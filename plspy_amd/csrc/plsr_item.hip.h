@@ -38,6 +38,7 @@ constexpr int LV_LD = 34;     // padded LDS row (conflict-free row-strided ds_re
 // in registers, so only the LDS write sits between the two barriers.
 template <int MC, int NI, int IG, int WV>
 __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
+  const bool want_nsq = A.nsq_part != nullptr;     // (uniform; the column norms usually come from K4f already)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc) {
           const double a = Vs[((ig * MC + mc) * 16 + col) * LV_LD + 4 * s + g];   // A[m = j][k = v]
-          nsq[ig][mc] = fma(a, a, nsq[ig][mc]);
+          if (want_nsq) nsq[ig][mc] = fma(a, a, nsq[ig][mc]);
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) acc[ig][mc][ni] = mfma_f64(a, b[ni], acc[ig][mc][ni]);
         }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
           const int i = (wave * NI + ni) * 16 + col;
           if (j < A.k && i < A.n) zo[(int64_t)j * A.n + i] = acc[ig][mc][ni][r];
         }
-    if (wave == 0) {
+    if (wave == 0 && want_nsq) {
 #pragma unroll
       for (int mc = 0; mc < MC; ++mc) {
         double x = nsq[ig][mc];

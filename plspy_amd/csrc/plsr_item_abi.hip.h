@@ -85,7 +85,7 @@ extern "C" size_t plsr_latent_workspace_bytes(int32_t n, int32_t k, int32_t item
 extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const double *d_vst,
                            int64_t ldv, int32_t items, int32_t k, double *d_Zt, double *d_nsq,
                            void *d_work, size_t work_bytes, void *stream) {
-  if (!d_X || !d_vst || !d_Zt || !d_nsq || !d_work || ldx < p || ldv < p) return PLSR_EINVAL;
+  if (!d_X || !d_vst || !d_Zt || !d_work || ldx < p || ldv < p) return PLSR_EINVAL;
   LatentPlan pl;
   if (!latent_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
   if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
@@ -100,7 +100,7 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
   a.ldv = ldv;
   a.tiles_per_chunk = pl.tiles_per_chunk;
   a.Zt_part = (double *)d_work;
-  a.nsq_part = a.Zt_part + pl.z_elems;
+  a.nsq_part = d_nsq ? a.Zt_part + pl.z_elems : nullptr;
   hipStream_t st = (hipStream_t)stream;
   int rc = PLSR_EUNSUPPORTED;
 #define PLSR_L(M, N) \
@@ -111,8 +111,9 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
   const int64_t EZ = (int64_t)items * k * n, EN = (int64_t)items * k;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EZ + 255) / 256), 1), dim3(256), 0, st,
                      (const double *)a.Zt_part, d_Zt, EZ, pl.nchunk, pl.nchunk);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
-                     (const double *)a.nsq_part, d_nsq, EN, pl.nchunk, pl.nchunk);
+  if (d_nsq)
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
+                       (const double *)a.nsq_part, d_nsq, EN, pl.nchunk, pl.nchunk);
   return launch_ok();
 }
 

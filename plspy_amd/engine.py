@@ -421,9 +421,8 @@ class ProjectionEngine:
             if need2 == 0:
                 raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
             work2 = torch.empty(need2, dtype=torch.uint8, device=self.device)
-            nsq2 = torch.empty((cnt, k), dtype=torch.float64, device=self.device)
             _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
-                                            k, _ptr(Zt[lo:hi]), _ptr(nsq2), _ptr(work2), need2,
+                                            k, _ptr(Zt[lo:hi]), _ptr(None), _ptr(work2), need2,
                                             _stream()), "plsr_latent")
             if on_batch is not None:
                 ev = torch.cuda.Event()
