@@ -38,8 +38,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix peak (AMD data sheet; the
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-iters", type=int, default=120, help="oracle iterations per loop for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -149,6 +149,12 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    # setup, before the W warm-up steps: first-use allocations of the scratch and the
+    # device's clock ramp -- from idle the same kernels take 3.1 ms instead of 2.7 ms for the
+    # first ~25 ms of load (measured: --warmup 0 / 1 / 2 / 3 / 5 -> 16.4 / 5.57 / 5.33 / 5.21 /
+    # 4.95 ms for the step that follows), so a short W would time the ramp, not the path
+    for _ in range(8):
+        step()
     for _ in range(args.warmup):
         step()
     fence()

@@ -10,7 +10,8 @@
 
 ``--count`` sets the number of resamples per loop (BASELINE's full counts are
 2000/2000, 1000 splits, 5000/5000); rates are per second of the resampling
-phase, host index generation and operator construction included.  Prints one
+phase, host index generation and operator construction included, from the second
+of two runs of each phase (the first, cold run is reported beside it).  Prints one
 JSON object per run."""
 import argparse
 import json
@@ -29,13 +30,24 @@ def data(n, p, b=0):
     return X, Y
 
 
-def timed(fn):
+COLD = {}          # label -> seconds of the first (cold) run of a timed phase
+
+
+def timed(fn, label=None):
+    """Runs fn twice and returns the second run's result and time: the first run of a phase in
+    a fresh process also pays the first-use device allocations of its scratch (hipMalloc and
+    first touch of several GiB: 0.2-0.7 s on some boxes of the pool, 0 on others), which is a
+    property of the box, not of the path.  The cold time is reported beside it (COLD)."""
     import torch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = fn()
-    torch.cuda.synchronize()
-    return out, time.perf_counter() - t0
+    for rep in range(2 if label else 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if label and rep == 0:
+            COLD[label] = dt
+    return out, dt
 
 
 def main():
@@ -63,8 +75,8 @@ def main():
         eng = ProjectionEngine(X)
         U, s, V = res.V, res.s.copy(), res.U
         co = np.array([[g] * 3 for g in groups])
-        rt, t_rs = timed(lambda: ResampleTest._create("mct", X, None, U, s, V, co, 0, nperm=R, nboot=R,
-                                                      Tvsc_orig=np.zeros((len(s), len(s))), engine=eng))
+        rt, t_rs = timed(lambda: ResampleTest._create("mct", X, None, U, s.copy(), V, co, 0, nperm=R, nboot=R,
+                                                      Tvsc_orig=np.zeros((len(s), len(s))), engine=eng), "resampling")
         out.update(seconds_resampling=t_rs, resamples_per_s=2 * R / t_rs)
     elif args.config == 3:
         R = args.count or 2000
@@ -73,9 +85,10 @@ def main():
         U, s, V = res.V, res.s.copy(), res.U
         co = np.array([[20] * 3, [20] * 3])
         eng = ProjectionEngine(X)
-        rt, t_perm = timed(lambda: ResampleTest._create("rb", X, Y, U, s, V, co, None, nperm=R, nboot=0, engine=eng))
-        rt, t_boot = timed(lambda: ResampleTest._create("rb", X, Y, U, s, V, co, None, nperm=0, nboot=R,
-                                                        lvcorrs_orig=res.lvcorrs, engine=eng))
+        rt, t_perm = timed(lambda: ResampleTest._create("rb", X, Y, U, s.copy(), V, co, None, nperm=R, nboot=0,
+                                                        engine=eng), "perm")
+        rt, t_boot = timed(lambda: ResampleTest._create("rb", X, Y, U, s.copy(), V, co, None, nperm=0, nboot=R,
+                                                        lvcorrs_orig=res.lvcorrs, engine=eng), "boot")
         out.update(workload=f"rb X=120x200000 Y=120x8 (k=48), {R} perm + {R} boot", seconds_observed=t_obs,
                    seconds_perm=t_perm, seconds_boot=t_boot, perms_per_s=R / t_perm, boots_per_s=R / t_boot,
                    resamples_per_s=2 * R / (t_perm + t_boot))
@@ -85,8 +98,8 @@ def main():
         co = np.array([[20] * 3, [20] * 3])
         eng = ProjectionEngine(X)
         kw = dict(mctype=0, bscan=[1, 2], engine=eng)
-        _, t_tt = timed(lambda: sh.split_half_test_train("mb", X, Y, co, S, **kw))
-        _, t_sh = timed(lambda: sh.split_half("mb", X, Y, co, S, lv=2, CI=0.95, **kw))
+        _, t_tt = timed(lambda: sh.split_half_test_train("mb", X, Y, co, S, **kw), "test_train")
+        _, t_sh = timed(lambda: sh.split_half("mb", X, Y, co, S, lv=2, CI=0.95, **kw), "split_half")
         out.update(workload=f"mb X=120x200000 Y=120x8 bscan=[1,2] (k=38), {S} splits (tt + sh, real + null)",
                    seconds_test_train=t_tt, seconds_split_half=t_sh, splits_per_s=S / (t_tt + t_sh))
     elif args.config == 6:
@@ -96,14 +109,14 @@ def main():
         X, Y = data(120, 200_000, 8)
         mk = lambda nperm, nboot: plspy_amd.PLS(X, [20, 20], 3, Y=Y, num_perm=nperm, num_boot=nboot,
                                                 pls_method="mb", bscan=[1, 2])
-        _, t_obs = timed(lambda: mk(0, 0))
-        _, t_obs = timed(lambda: mk(0, 0))                       # warm
-        _, t_p = timed(lambda: mk(R, 0))
-        _, t_b = timed(lambda: mk(0, R))
+        _, t_obs = timed(lambda: mk(0, 0), "observed")
+        _, t_p = timed(lambda: mk(R, 0), "perm")
+        _, t_b = timed(lambda: mk(0, R), "boot")
         t_perm, t_boot = t_p - t_obs, t_b - t_obs                # the observed decomposition is in both
         out.update(workload=f"mb X=120x200000 Y=120x8 bscan=[1,2] (k=38), {R} perm + {R} boot",
                    seconds_observed=t_obs, seconds_perm=t_perm, seconds_boot=t_boot, perms_per_s=R / t_perm,
                    boots_per_s=R / t_boot)
+    out["seconds_cold_first_run"] = COLD
     print(json.dumps(out))
 
 

@@ -62,7 +62,7 @@ if tr:
         if "project_" in r["Kernel_Name"]:
             per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     line = [l for l in open(os.path.join(src, "stats.log")) if l.startswith("{")]
-    out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu",
+    out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu  (8 spin-up + 5 warm-up + 40 timed launches per kernel)",
            "per_launch_ms_in_launch_order": per,
            "bench_line_of_the_same_run": json.loads(line[-1]) if line else None}
     json.dump(out, open(os.path.join(dst, f"{tag}_project_kernel_launches.json"), "w"), indent=1)
