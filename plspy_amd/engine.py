@@ -7,6 +7,7 @@ torch.distributed only; every arithmetic step on the resampling path is a
 hand-written gfx950 kernel behind the ABI."""
 import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,9 @@ def _ptr(t):
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+
+# scratch one batch may use (bytes); PLSR_WORK_LIMIT_GIB overrides the default
+DEFAULT_WORK_LIMIT = int(float(os.environ.get("PLSR_WORK_LIMIT_GIB", "24")) * (1 << 30))
 
 _SIDE_STREAMS = {}
 
@@ -53,7 +57,7 @@ class ProjectionEngine:
     work_limit bounds the scratch a single batch may use; larger phases are
     cut into batches of resamples (each batch is one kernel launch)."""
 
-    def __init__(self, X, device=None, work_limit=24 << 30):
+    def __init__(self, X, device=None, work_limit=None):
         if not torch.cuda.is_available():
             raise RuntimeError("plspy_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.lib = _lib.load()
@@ -63,7 +67,7 @@ class ProjectionEngine:
             raise ValueError("X must be 2-dimensional")
         self.X = X.to(device=self.device, dtype=torch.float64).contiguous()
         self.n, self.p = self.X.shape
-        self.work_limit = int(work_limit)
+        self.work_limit = int(work_limit) if work_limit is not None else DEFAULT_WORK_LIMIT
         self._lanes = {}
         self._tail = None
         self._h2d = None
