@@ -590,7 +590,7 @@ bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, bool per_item_x, 
   {
     const size_t ops = (size_t)g.B * g.MC * nk * 512;
     const int fit = (int)((160 * 1024 - ops) / 2048);
-    g.ks = std::min(nk, fit);
+    g.ks = std::min(std::min(nk, fit), GRAM_PF);      // a thread parks ks rows of the next chunk in registers
     if (g.ks < 1) return false;
   }
   g.lds = gram_lds_bytes(nk, g.MC, g.B, g.ks);

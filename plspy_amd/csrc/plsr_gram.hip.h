@@ -44,6 +44,8 @@ struct GramArgs {
   const double *sc, *sh;     // [items][ncell][p]
 };
 
+constexpr int GRAM_PF = 20;   // rows of X a thread parks in registers per K-chunk (ks <= GRAM_PF)
+
 // MC = 16-row tiles per item, B = items per workgroup
 template <int MC, int B, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
@@ -85,93 +87,166 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
   const int64_t t_hi = min(nvt, t_lo + A.tiles_per_chunk);
   const int xo = xs_index(g, wave * 16 + col);          // A operand: voxel = col of this wave's 16, row = g
 
-  for (int64_t vt = t_lo; vt < t_hi; ++vt) {
-    const int64_t v0 = vt * TV;
-    f64x4 D[B][MC];
+  // The rows of X are staged K-chunk by K-chunk ((voxel tile, chunk) pairs in sequence).
+  // The global loads of pair i + 1 are issued BEFORE the MFMAs of pair i and parked in
+  // registers (px / psc / psh), so that between the two barriers of a pair only the LDS
+  // writes remain: with one workgroup per CU nothing else would hide the HBM latency of
+  // the staging (it used to cost as much as the MFMAs of a chunk).
+  // Row u of a wave's share: FUSED -- a run of consecutive rows (rbeg + u), gathered
+  // through src and z-scored at parking time with the (cell, voxel) scale / shift, which
+  // are loaded per row (clamped addresses, no branches); plain -- rows 4 ks0 + 4 u + wave.
+  struct Pos {
+    int64_t vt;
+    int ks0;
+  };
+  auto advance = [&](Pos q) {
+    q.ks0 += A.ks;
+    if (q.ks0 >= A.nk) {
+      q.ks0 = 0;
+      ++q.vt;
+    }
+    return q;
+  };
+  double px[GRAM_PF], psc[FUSED ? GRAM_PF : 1], psh[FUSED ? GRAM_PF : 1];
+  // FUSED: the item's source-row and cell tables (n <= 256 entries each) live in four
+  // vector registers apiece, entry r in lane r & 63 of register r >> 6; a row's entry
+  // comes out through v_readlane.  Read from memory per row they were dependent loads
+  // in front of every X load -- one L2 round trip per row, which cost more than the
+  // MFMAs of a chunk.
+  int sreg[4] = {0, 0, 0, 0}, creg[4] = {0, 0, 0, 0};
+  if (FUSED) {
+    const int32_t *srci = A.src + (int64_t)item0 * A.n;
 #pragma unroll
-    for (int b = 0; b < B; ++b)
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 64 + lane;
+      sreg[q] = idx < A.n ? srci[idx] : 0;
+      creg[q] = idx < A.n ? A.rowcell[idx] : 0;
+    }
+  }
+  auto pick = [&](const int (&t)[4], int row) {          // row is wave-uniform
+    const int l = row & 63, qd = row >> 6;
+    // four v_readlane and scalar selects (a select between the vector registers
+    // compiled to a chain of branches)
+    const int r0 = __builtin_amdgcn_readlane(t[0], l), r1 = __builtin_amdgcn_readlane(t[1], l);
+    const int r2 = __builtin_amdgcn_readlane(t[2], l), r3 = __builtin_amdgcn_readlane(t[3], l);
+    return qd == 0 ? r0 : (qd == 1 ? r1 : (qd == 2 ? r2 : r3));
+  };
+  auto fetch = [&](Pos q) {
+    const int ks1 = min(A.nk, q.ks0 + A.ks);
+    const int64_t v = q.vt * TV + lane;
+    const bool vin = v < A.p && q.vt < t_hi;
+    const int64_t vc = min(v, A.p - 1);
+    if (FUSED) {
+      const int rpw = (4 * (ks1 - q.ks0) + WAVES - 1) / WAVES;
+      const int rbeg = 4 * q.ks0 + wave * rpw;
+      const int rend = min(4 * ks1, rbeg + rpw);
 #pragma unroll
-      for (int mc = 0; mc < MC; ++mc) D[b][mc] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    for (int ks0 = 0; ks0 < A.nk; ks0 += A.ks) {
-      const int ks1 = min(A.nk, ks0 + A.ks);
-      __syncthreads();                                  // previous X chunk fully consumed (and ops written)
-      if (FUSED) {
-        // every wave stages a run of consecutive rows: the scale / shift of a cell
-        // are then loaded once per cell and chunk, not once per element
-        const int rows_chunk = 4 * (ks1 - ks0);
-        const int rpw = (rows_chunk + WAVES - 1) / WAVES;
-        const int rbeg = 4 * ks0 + wave * rpw;
-        const int rend = min(4 * ks1, rbeg + rpw);
-        const int64_t v = v0 + lane;
-        const bool vin = v < A.p;
-        const int32_t *srci = A.src + (int64_t)item0 * A.n;
-        int ccur = -1;
-        double scv = 0.0, shv = 0.0;
-        for (int r = rbeg; r < rend; r += 4) {
-          double xv[4];
-          int cc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int row = r + u;
-            const bool ok = row < rend && row < A.n;
-            cc[u] = ok ? A.rowcell[row] : -1;
-            xv[u] = (ok && vin) ? A.X[(int64_t)srci[ok ? row : 0] * A.ldx + v] : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int row = r + u;
-            if (row < rend) {
-              double val = 0.0;
-              if (cc[u] >= 0) {
-                if (cc[u] != ccur) {
-                  ccur = cc[u];
-                  const int64_t sidx = ((int64_t)item0 * A.ncell + ccur) * A.p + min(v, A.p - 1);
-                  scv = A.sc[sidx];
-                  shv = A.sh[sidx];
-                }
-                val = vin ? fma(xv[u], scv, shv) : 0.0;
-              }
-              Xs[xs_index(row - 4 * ks0, lane)] = val;
-            }
-          }
-        }
-      } else
-      for (int r0 = 4 * ks0; r0 < 4 * ks1; r0 += 16) {
-        double tmp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = r0 + u * 4 + (tid >> 6);
-          const int64_t v = v0 + lane;
-          tmp[u] = (row < A.n && v < A.p) ? Xi[(int64_t)row * A.ldx + v] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = r0 + u * 4 + (tid >> 6);
-          if (row < 4 * ks1) Xs[xs_index(row - 4 * ks0, lane)] = tmp[u];
-        }
+      for (int u = 0; u < GRAM_PF; ++u) {
+        const int row = rbeg + u;
+        const bool ok = row < rend && row < A.n;
+        const int rc = ok ? row : 0;
+        const int cell = pick(creg, rc);
+        const int64_t sidx = ((int64_t)item0 * A.ncell + cell) * A.p + vc;
+        const double x = A.X[(int64_t)pick(sreg, rc) * A.ldx + vc];
+        const double c = A.sc[sidx], h = A.sh[sidx];
+        px[u] = (ok && vin) ? x : 0.0;
+        psc[u] = (ok && vin) ? c : 0.0;
+        psh[u] = (ok && vin) ? h : 0.0;
       }
-      __syncthreads();
-      for (int s = ks0; s < ks1; ++s) {
-        const double a = Xs[(size_t)(s - ks0) * 4 * TV + xo];
+    } else {
+#pragma unroll
+      for (int u = 0; u < GRAM_PF; ++u) {
+        const int row = 4 * q.ks0 + 4 * u + wave;
+        const bool ok = row < 4 * ks1 && row < A.n;
+        const double x = Xi[(int64_t)(ok ? row : 0) * A.ldx + vc];
+        px[u] = (ok && vin) ? x : 0.0;
+      }
+    }
+  };
+  auto park = [&](Pos q) {
+    const int ks1 = min(A.nk, q.ks0 + A.ks);
+    if (FUSED) {
+      const int rpw = (4 * (ks1 - q.ks0) + WAVES - 1) / WAVES;
+      const int rbeg = 4 * q.ks0 + wave * rpw;
+      const int rend = min(4 * ks1, rbeg + rpw);
+#pragma unroll
+      for (int u = 0; u < GRAM_PF; ++u) {
+        const int row = rbeg + u;
+        if (row < rend) Xs[xs_index(row - 4 * q.ks0, lane)] = fma(px[u], psc[FUSED ? u : 0], psh[FUSED ? u : 0]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < GRAM_PF; ++u) {
+        const int row = 4 * q.ks0 + 4 * u + wave;
+        if (row < 4 * ks1) Xs[xs_index(row - 4 * q.ks0, lane)] = px[u];
+      }
+    }
+  };
+
+  f64x4 D[B][MC];
+  Pos cur{t_lo, 0};
+  if (t_lo < t_hi) fetch(cur);
+  while (cur.vt < t_hi) {
+    const int ks0 = cur.ks0;
+    const int ks1 = min(A.nk, ks0 + A.ks);
+    if (ks0 == 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) D[b][mc] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
+    __syncthreads();                                    // previous X chunk fully consumed (and ops written)
+    park(cur);
+    __syncthreads();
+    const Pos nxt = advance(cur);
+    fetch(nxt);                                         // in flight during the MFMAs below
+    {
+      // software pipeline: the operands of k-step s + 1 are read from LDS before the
+      // MFMAs of step s are issued (at one wave per SIMD nothing else hides the LDS
+      // latency; left to itself the compiler reads and waits inside every step).  Two
+      // register sets in turn, so that no copies sit between the loads and the MFMAs;
+      // the last step of a chunk prefetches itself again (the next chunk is not staged yet).
+      auto ld = [&](int sidx, double &a, double (&bv)[B][MC]) {
+        a = Xs[(size_t)(sidx - ks0) * 4 * TV + xo];
 #pragma unroll
         for (int b = 0; b < B; ++b)
 #pragma unroll
-          for (int mc = 0; mc < MC; ++mc)
-            D[b][mc] = mfma_f64(a, ops[((size_t)(b * MC + mc) * A.nk + s) * 64 + lane], D[b][mc]);
+          for (int mc = 0; mc < MC; ++mc) bv[b][mc] = ops[((size_t)(b * MC + mc) * A.nk + sidx) * 64 + lane];
+      };
+      auto mm = [&](double a, double (&bv)[B][MC]) {
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) D[b][mc] = mfma_f64(a, bv[b][mc], D[b][mc]);
+      };
+      double a0, a1, b0[B][MC], b1[B][MC];
+      ld(ks0, a0, b0);
+      int s = ks0;
+      for (; s + 2 <= ks1; s += 2) {
+        ld(s + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0);
+        ld(min(s + 2, ks1 - 1), a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
+      }
+      if (s < ks1) mm(a0, b0);
+    }
+    if (ks1 == A.nk) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        int idx = 0;
+#pragma unroll
+        for (int m1 = 0; m1 < MC; ++m1)
+#pragma unroll
+          for (int m2 = m1; m2 < MC; ++m2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G[b][idx] = mfma_f64(D[b][m1][r], D[b][m2][r], G[b][idx]);
+            ++idx;
+          }
       }
     }
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      int idx = 0;
-#pragma unroll
-      for (int m1 = 0; m1 < MC; ++m1)
-#pragma unroll
-        for (int m2 = m1; m2 < MC; ++m2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) G[b][idx] = mfma_f64(D[b][m1][r], D[b][m2][r], G[b][idx]);
-          ++idx;
-        }
-    }
+    cur = nxt;
   }
 
   // ---- sum the four waves' Gram tiles through LDS and write the slab ----

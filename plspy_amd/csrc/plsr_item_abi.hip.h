@@ -326,6 +326,7 @@ bool gram_fused_plan(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo, c
   if (n <= 0 || !cell_lo || ncell <= 0 || ncell > FZ_MAXCELL || cell_lo[0] != 0 || cell_lo[ncell] != nz)
     return false;
   if ((size_t)n * TV * sizeof(double) > 160 * 1024) return false;        // statistics kernel's X tile
+  if (nz > 256) return false;          // the fused Gram keeps the source-row / cell tables in four registers apiece
   if (!gram_plan(nz, m, items, p, true, pl.g)) return false;
   pl.cells.ncell = ncell;
   int steps = 0;
