@@ -559,18 +559,23 @@ __global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) 
     // acc[nt][r] = VS_b[voxel 16 nt + g + 4 r][j],  b = 16 (t - j tpl) + col
     // (scheduling barriers keep the epilogue's LDS operands from being hoisted all
     // at once next to the resident X fragments: that spilled)
+    // column norms first; the second-moment LDS atomics come LAST in the epilogue: LDS
+    // operations of a wave complete in order, so every later s_waitcnt lgkmcnt -- the two
+    // cross-lane adds below, the cell-mean reads of the T product -- would also wait for
+    // sixteen ds_add_f64 issued in front of them
+    // (the first cell-mean operands of the T product are read here, so that their LDS
+    // latency passes under the norm computation)
+    double xn[NT];
+    {
+      const double *xm0 = smem + (lane & 3) * XM_LD + g;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xn[nt] = xm0[16 * nt];
+    }
     double q = 0.0;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double sq = acc[nt][r] * acc[nt][r];
-        // ds_add_f64 without return: lane-private slot, so the order of additions is
-        // program order (deterministic), and no register or wait is spent on it
-        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(s2 + (4 * nt + r) * 64), sq);
-        q += sq;
-      }
-    }
+      for (int r = 0; r < 4; ++r) q = fma(acc[nt][r], acc[nt][r], q);
     q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 32);
     // stores are unconditional (idle lanes write a sink, see K1r) and fixed in number,
@@ -588,12 +593,10 @@ __global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) 
       // T[cell 4 h + i][column 4 b + jj] lands at lane 16 i + 4 b + jj = (g = i, col).
       // Four independent accumulation chains (one per voxel tile): a single chain of
       // sixteen dependent 4x4x4 MFMAs would expose the MFMA latency sixteen times.
-      // The cell-mean operands of group r + 1 are read while group r multiplies.
+      // The cell-mean operands of the next step (r + 1, or the first of group h + 1) are
+      // read while this step multiplies.
       double aT[NT] = {0.0, 0.0, 0.0, 0.0};
       const double *xm = smem + (4 * h + (lane & 3)) * XM_LD + g;
-      double xn[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) xn[nt] = xm[16 * nt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double xc[NT];
@@ -602,6 +605,9 @@ __global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) 
         if (r < 3) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) xn[nt] = xm[16 * nt + 4 * (r + 1)];
+        } else if (h + 1 < nh) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) xn[nt] = xm[4 * XM_LD + 16 * nt];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -618,6 +624,16 @@ __global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) 
         double *dst = cell < A.k2 ? tp + cell : A.sink + lane;
         *dst = Tout[h];
       }
+    }
+    // second moment: ds_add_f64 without return on lane-private slots -- the order of
+    // additions is program order (deterministic), and no register or wait is spent on it
+    // (nothing reads LDS again before the next tile's epilogue)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(s2 + (4 * nt + r) * 64),
+                                            acc[nt][r] * acc[nt][r]);
     }
     if (DUMP) {
       const int64_t b = (int64_t)(t - j * A.tpl) * 16 + col;
