@@ -461,6 +461,9 @@ __global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(xa[s][nt], b, acc[nt]);
       fr[s] = an[(size_t)s * 64];
+      // keep the refill where it is written: left alone the scheduler sinks most of the
+      // fifteen loads to the end of the tile, three k-steps before their first use
+      __builtin_amdgcn_sched_barrier(0);
     }
     // acc[nt][r] = VS[batch column col][voxel 16 nt + g + 4 r]
     double q = 0.0;
