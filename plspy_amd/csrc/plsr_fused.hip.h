@@ -37,6 +37,7 @@
 namespace plsr {
 
 constexpr int FZ_MAXCELL = 64;
+constexpr int STATS_REG_ROWS = 32;   // cells up to this many rows take the statistics kernel's register path
 
 struct FusedCells {
   int32_t ncell, nkp;                  // cells, padded k-steps per item
@@ -70,7 +71,19 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
   const int it_hi = min(A.items, it_lo + per);
   const int ncell = A.cells.ncell;
   // (item, cell) pairs round-robin over the four waves
+  // source rows of a pair's cell (lane r: row lo + r), fetched one pair ahead so that the
+  // global load's latency passes under the previous pair's arithmetic
+  auto cell_rows = [&](int e2) {
+    if (e2 >= it_hi * ncell) return 0;
+    const int item2 = e2 / ncell;
+    const int c2 = e2 - item2 * ncell;
+    const int lo2 = A.cells.row_lo[c2], hi2 = A.cells.row_lo[c2 + 1];
+    return lane < hi2 - lo2 ? A.src[(int64_t)item2 * A.nz + lo2 + lane] * TV : 0;
+  };
+  int mine_next = cell_rows(it_lo * ncell + wave);
   for (int e = it_lo * ncell + wave; e < it_hi * ncell; e += WAVES) {
+    const int mine0 = mine_next;
+    mine_next = cell_rows(e + WAVES);
     const int item = e / ncell;
     const int c = e - item * ncell;
     const int lo = A.cells.row_lo[c], hi = A.cells.row_lo[c + 1];
@@ -83,6 +96,38 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
       // memory latency of its own
       // (four independent partial sums: four LDS reads in flight per wave)
       auto at = [&](int mine, int r) { return smem[__builtin_amdgcn_readlane(mine, r) + lane]; };
+      double mu, var;
+      if (hi - lo <= STATS_REG_ROWS) {
+        // a cell of at most 32 rows is read from LDS ONCE, every read in flight at the same
+        // time, and both passes run on registers (the two-pass loops below keep four reads
+        // in flight and read every row twice: latency-bound)
+        const int mine = mine0;
+        const int m = hi - lo;
+        double x[STATS_REG_ROWS];
+#pragma unroll
+        for (int r = 0; r < STATS_REG_ROWS; ++r) x[r] = r < m ? at(mine, r) : 0.0;
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < STATS_REG_ROWS; r += 4) {
+          m0 += x[r];
+          m1 += x[r + 1];
+          m2 += x[r + 2];
+          m3 += x[r + 3];
+        }
+        mu = ((m0 + m1) + (m2 + m3)) / cnt;
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < STATS_REG_ROWS; r += 4) {
+          // (rows past the cell hold 0: their deviation is masked, not subtracted)
+          const double d0 = r < m ? x[r] - mu : 0.0, d1 = r + 1 < m ? x[r + 1] - mu : 0.0;
+          const double d2 = r + 2 < m ? x[r + 2] - mu : 0.0, d3 = r + 3 < m ? x[r + 3] - mu : 0.0;
+          q0 = fma(d0, d0, q0);
+          q1 = fma(d1, d1, q1);
+          q2 = fma(d2, d2, q2);
+          q3 = fma(d3, d3, q3);
+        }
+        var = (q0 + q1) + (q2 + q3);
+      } else {
       double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
       for (int r0 = lo; r0 < hi; r0 += 64) {
         const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
@@ -96,7 +141,7 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
         }
         for (; r < m; ++r) m0 += at(mine, r);
       }
-      const double mu = ((m0 + m1) + (m2 + m3)) / cnt;
+      mu = ((m0 + m1) + (m2 + m3)) / cnt;
       double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
       for (int r0 = lo; r0 < hi; r0 += 64) {
         const int mine = r0 + lane < hi ? src[r0 + lane] * TV : 0;
@@ -115,7 +160,8 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
           q0 = fma(d, d, q0);
         }
       }
-      const double var = (q0 + q1) + (q2 + q3);
+      var = (q0 + q1) + (q2 + q3);
+      }
       const double sd = sqrt(var / cnt);
       // scipy.stats.zscore's constant-slice rule followed by nan_to_num -> 0
       const bool dead = !(sd > 2.220446049250313e-16 * fabs(mu));
