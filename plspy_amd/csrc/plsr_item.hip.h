@@ -28,7 +28,7 @@ struct LatentArgs {
 };
 
 constexpr int LV_T = 32;      // voxels per staged tile
-constexpr int LV_LD = 34;     // padded LDS row (conflict-free row-strided ds_read_b64)
+constexpr int LV_LD = 33;     // padded LDS row: SQ_LDS_BANK_CONFLICT is 0 with 33; with 34 it was 45 % of the LDS cycles
 
 // MC = 16-row tiles of latent variables; NI = 16-row tiles of data rows per wave;
 // IG = items per workgroup: they share every staged X tile (X is re-read once
