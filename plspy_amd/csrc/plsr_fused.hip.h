@@ -37,6 +37,10 @@
 namespace plsr {
 
 constexpr int FZ_MAXCELL = 64;
+#ifndef PLSR_FZ_RING
+#define PLSR_FZ_RING 4
+#endif
+constexpr int FZ_RING = PLSR_FZ_RING;   // k-steps the operator-fragment ring of item_fused_kernel runs ahead (4 or 8; 8 measured 10 % slower at config 3: more scratch)
 constexpr int STATS_REG_ROWS = 32;   // cells up to this many rows take the statistics kernel's register path
 
 struct FusedCells {
@@ -331,9 +335,9 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
   const double *fp = A.frag + ((size_t)mc * A.items * nkp + (size_t)it_lo * nkp) * 64 + lane;
   const int32_t *rp = tbl + g;           // LDS: byte offset of the row of (step, lane group)
   int64_t pos = (int64_t)(sa - it_lo) * nkp;    // stream position of the current cell's first step
-  double ra[4];
+  double ra[FZ_RING];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) ra[u] = fp[(size_t)(pos + u) * 64];
+  for (int u = 0; u < FZ_RING; ++u) ra[u] = fp[(size_t)(pos + u) * 64];
   double bn[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + rp[pos * 4] + nt * 128);
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(ra[u], z[nt], acc[nt]);
-        ra[u] = fq[(size_t)(sidx + 4) * 64];
+        ra[u] = fq[(size_t)(sidx + FZ_RING) * 64];
       };
 
       // A cell rarely has a multiple of four steps, so the ring slot of its first
@@ -401,23 +405,28 @@ __global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
       // instead the loop exists in four variants with static slot numbers.
       auto run = [&](auto ph) {
         constexpr int P = decltype(ph)::value;
+        constexpr int M = FZ_RING - 1;
         int s = 0;
-        for (; s + 4 <= ns; s += 4) {
+        for (; s + FZ_RING <= ns; s += FZ_RING) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) step(s + u, (P + u) & 3, (P + u + 1) & 3);
+          for (int u = 0; u < FZ_RING; ++u) step(s + u, (P + u) & M, (P + u + 1) & M);
         }
-        const int rem = ns & 3;
+        const int rem = ns & M;
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
-          if (u < rem) step(s + u, (P + u) & 3, (P + u + 1) & 3);
+        for (int u = 0; u < M; ++u)
+          if (u < rem) step(s + u, (P + u) & M, (P + u + 1) & M);
       };
       switch (phase) {
         case 0: run(std::integral_constant<int, 0>{}); break;
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        default: run(std::integral_constant<int, 3>{}); break;
+        case 1: run(std::integral_constant<int, 1 % FZ_RING>{}); break;
+        case 2: run(std::integral_constant<int, 2 % FZ_RING>{}); break;
+        case 3: run(std::integral_constant<int, 3 % FZ_RING>{}); break;
+        case 4: run(std::integral_constant<int, 4 % FZ_RING>{}); break;
+        case 5: run(std::integral_constant<int, 5 % FZ_RING>{}); break;
+        case 6: run(std::integral_constant<int, 6 % FZ_RING>{}); break;
+        default: run(std::integral_constant<int, 7 % FZ_RING>{}); break;
       }
-      phase = (phase + ns) & 3;
+      phase = (phase + ns) & (FZ_RING - 1);
       pos += ns;
     }
 
