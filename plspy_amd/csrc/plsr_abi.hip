@@ -192,7 +192,7 @@ struct Work {
 // column splits: pick the grid.y in 1..4 that wastes least in the last round of
 // workgroups (256 CUs x 2 resident workgroups), without splitting below one
 // wave x period group per workgroup
-int pick_split(const plsr_layout_t *lay, int64_t nvt) {
+int pick_split(const plsr_layout_t *lay, int64_t nvt, int nw) {
   if (lay->period == 0) {
     // LV-major layout (K1br): splits per latent variable, for about ten rounds of
     // the 2048 resident waves (one wave per workgroup, grid.y = k * splits); measured
@@ -202,7 +202,7 @@ int pick_split(const plsr_layout_t *lay, int64_t nvt) {
     const int64_t want = (10 * 2048 + nvt * lay->k - 1) / (nvt * lay->k);
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max(1, tpl / 4)));
   }
-  const int groups = (lay->ntiles + WAVES * lay->period - 1) / (WAVES * lay->period);
+  const int groups = (lay->ntiles + nw * lay->period - 1) / (nw * lay->period);
   int best = 1;
   double best_eff = 0.0;
   for (int c = 1; c <= 4 && c <= groups; ++c) {
@@ -220,7 +220,10 @@ Work carve(const plsr_layout_t *lay, int64_t p, int32_t k2, void *base, bool boo
   Work w;
   w.nvt = (p + TV - 1) / TV;
   w.C = (int64_t)lay->ntiles * 16;
-  w.nsplit = pick_split(lay, w.nvt);
+  // (waves per workgroup of the LDS-fed kernel: the permutation launch runs the period-1 instance)
+  const int nw = lay->period == 0 ? WAVES
+                 : lds_fed_waves(lay->nk, boot ? lay->period : 1, boot, boot ? (k2 + 3) / 4 : 0, lay->kp);
+  w.nsplit = pick_split(lay, w.nvt, nw);
   w.nchunk = (int)((w.nvt + SLAB_CHUNK - 1) / SLAB_CHUNK);
   size_t off = 0;
   auto take = [&](size_t elems) {
@@ -252,7 +255,7 @@ int reduce_slabs(const double *slabs, const Work &w, int width, const plsr_layou
 
 using ProjectKernel = void (*)(ProjectArgs);
 
-int launch_kernel(ProjectKernel kern, int mode, const ProjectArgs &a, size_t lds, dim3 grid,
+int launch_kernel(ProjectKernel kern, int mode, const ProjectArgs &a, size_t lds, dim3 grid, int nw,
                   hipStream_t st) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern,
@@ -269,7 +272,7 @@ int launch_kernel(ProjectKernel kern, int mode, const ProjectArgs &a, size_t lds
     tl.kind = mode;
     (void)hipEventRecord(tl.a, st);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a);
   if (g_timing) {
     (void)hipEventRecord(tl.b, st);
     g_timed.push_back(tl);
@@ -292,7 +295,8 @@ ProjectKernel boot_instance(int nh) {
 
 template <int MODE>
 int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hipStream_t st) {
-  size_t lds = project_lds_bytes(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp);
+  const int nw = lds_fed_waves(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp);
+  size_t lds = project_lds_bytes(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp, nw);
 #if PLSR_ABLATE & 256
   if (MODE == 0) lds += 40 * 1024;   // dev: force the permutation kernel down to two workgroups per CU
 #endif
@@ -312,7 +316,7 @@ int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hi
       default: return PLSR_EUNSUPPORTED;
     }
   }
-  return launch_kernel(kern, MODE, a, lds, grid, st);
+  return launch_kernel(kern, MODE, a, lds, grid, nw, st);
 }
 template <bool DUMP, int NHT>
 ProjectKernel boot_reg_instance(int nk) {

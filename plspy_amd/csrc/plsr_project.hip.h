@@ -79,13 +79,16 @@ __device__ __forceinline__ int xs_index(int row, int v) {
 // hot bootstrap instance (a run-time count in the unrolled MFMA loop costs ~15 %);
 // -1 = take it from the arguments (dump mode), 0 = no second matrix.
 template <int PERIOD, int MODE, int NHT>
-__global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
+__global__ __launch_bounds__(512, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
   constexpr bool BOOT = MODE != 0;
   constexpr bool DUMP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // four waves per workgroup, or eight when the X tile leaves room for one workgroup per CU
+  // only (n > 144): two waves per SIMD instead of one (lds_fed_waves)
+  const int NW = blockDim.x >> 6;
   const int col = lane & 15;
   const int g = lane >> 4;
   const int64_t vt = blockIdx.x;
@@ -96,17 +99,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
   double *Dt = smem + (size_t)nrows * TV + (size_t)wave * 16 * DT_LD;
 
   // ---- stage X[:, v0 : v0+64] (zero padded in both directions) ----
-  for (int r0 = 0; r0 < nrows; r0 += 4 * 4) {
+  for (int r0 = 0; r0 < nrows; r0 += 4 * NW) {
     double tmp[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int row = r0 + u * 4 + (tid >> 6);
+      const int row = r0 + u * NW + wave;
       const int64_t v = v0 + lane;
       tmp[u] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int row = r0 + u * 4 + (tid >> 6);
+      const int row = r0 + u * NW + wave;
       if (row < nrows) Xs[xs_index(row, lane)] = tmp[u];
     }
   }
@@ -127,17 +130,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
   // same LDS word (broadcast) and the padded row (XM_LD = 72) puts the four cells of a
   // half 16 banks apart, so the read is conflict free.  Shared by the four waves.
   const int nh = NHT >= 0 ? NHT : (A.k2 + 3) / 4;                         // halves of 4 cells
-  double *XmS = smem + (size_t)nrows * TV + (size_t)WAVES * 16 * DT_LD;   // [4 nh cells][XM_LD]
+  double *XmS = smem + (size_t)nrows * TV + (size_t)NW * 16 * DT_LD;   // [4 nh cells][XM_LD]
   // shift of the streaming moments (observed V*s), [kp][64 voxels], zero for padding
   double *RfS = XmS + (size_t)nh * 4 * XM_LD;
   double s1[PERIOD][NT], s2[PERIOD][NT];
   if (BOOT) {
-    for (int e = tid; e < A.kp * TV; e += 256) {
+    for (int e = tid; e < A.kp * TV; e += blockDim.x) {
       const int j = e >> 6;
       const int64_t v = v0 + (e & 63);
       RfS[e] = (A.ref != nullptr && j < A.k && v < A.p) ? A.ref[v * A.k + j] : 0.0;
     }
-    for (int cell = wave; cell < nh * 4; cell += WAVES) {
+    for (int cell = wave; cell < nh * 4; cell += NW) {
       const int64_t v = v0 + lane;
       XmS[cell * XM_LD + lane] =
           (A.Xm != nullptr && cell < A.k2 && v < A.p) ? A.Xm[(int64_t)cell * A.ldxm + v] : 0.0;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
   // PERIOD, so the slot -> latent-variable map holds): its operator fragments
   // are then one linear stream in memory.
   const int cs = blockIdx.y;
-  const int group = WAVES * PERIOD;
+  const int group = NW * PERIOD;
   const int gps = ((A.ntiles + group - 1) / group + gridDim.y - 1) / gridDim.y;
   const int t_begin = cs * gps * group;
   const int t_end = min(A.ntiles, t_begin + gps * group);
@@ -387,13 +390,13 @@ __global__ __launch_bounds__(256, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void proje
       }
       __syncthreads();
       double *out = (pass == 0 ? A.S1 : A.S2) + (int64_t)cs * A.p * A.k;
-      for (int e = tid; e < TV * A.k; e += 256) {
+      for (int e = tid; e < TV * A.k; e += blockDim.x) {
         const int vl = e / A.k;
         const int j = e % A.k;
         const int64_t v = v0 + vl;
         if (v >= A.p) continue;
         double sum = 0.0;
-        for (int w = 0; w < WAVES; ++w) {
+        for (int w = 0; w < NW; ++w) {
           for (int qq = j; qq < 4 * PERIOD; qq += A.kp)
             sum += red[((w * PERIOD + (qq >> 2)) * 4 + (qq & 3)) * TV + vl];
         }
@@ -724,11 +727,20 @@ __global__ __launch_bounds__(256) void moment_shift_merge_kernel(double *S1, dou
   S2[e] += fma(r, fma(cnt, r, -2.0 * a), b);
 }
 
-inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp) {
-  size_t a = ((size_t)nk * 4 * TV + (size_t)WAVES * 16 * DT_LD + (boot ? nh * 4 * XM_LD + kp * TV : 0)) *
+inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp, int nw = WAVES) {
+  size_t a = ((size_t)nk * 4 * TV + (size_t)nw * 16 * DT_LD + (boot ? nh * 4 * XM_LD + kp * TV : 0)) *
              sizeof(double);
-  size_t b = boot ? (size_t)WAVES * period * 4 * TV * sizeof(double) : 0;
+  size_t b = boot ? (size_t)nw * period * 4 * TV * sizeof(double) : 0;
   return a > b ? a : b;
+}
+
+// Waves per workgroup of the LDS-fed kernel: when the X tile alone (n x 64 doubles) takes
+// more than half of the CU's 160 KB only one workgroup is resident, and four waves would
+// leave each SIMD with a single wave (LDS-fed fp64 MFMA: 58 TFLOP/s at one wave per SIMD,
+// 66 at two, microbench/mfma_f64_data) -- eight waves then, if the per-wave patches still fit.
+inline int lds_fed_waves(int nk, int period, bool boot, int nh, int kp) {
+  if ((size_t)nk * 4 * TV * sizeof(double) <= 72 * 1024) return WAVES;
+  return project_lds_bytes(nk, period, boot, nh, kp, 2 * WAVES) <= 160 * 1024 ? 2 * WAVES : WAVES;
 }
 
 // ---------------------------------------------------------------------------

@@ -113,12 +113,15 @@ def test_projection_phases_random_shapes():
     the dumped VS for random n, k (all periods incl. padded ones), R, p."""
     from plspy_amd.engine import ProjectionEngine
     rs = np.random.RandomState(13)
-    for trial in range(20):
-        n = int(rs.randint(3, 70))
+    # the last eight trials have n > 144: the LDS-fed kernel then runs eight waves per
+    # workgroup (one workgroup per CU), up to the largest n whose tile still fits (256)
+    big_n = [145, 150, 197, 240, 240, 252, 256, 256]
+    for trial in range(28):
+        n = int(rs.randint(3, 70)) if trial < 20 else big_n[trial - 20]
         p = int(rs.choice([1, 63, 64, 65, 257]))
         k = int(rs.randint(1, 15))
         k2 = int(rs.randint(0, 13))
-        R = int(rs.randint(1, 30))
+        R = int(rs.randint(1, 30)) if trial < 20 else int(rs.randint(20, 90))
         X = rs.randn(n, p)
         M = rs.randn(n, k)
         inds = rs.randint(0, n, size=(R, n)).astype(np.int32)
