@@ -101,18 +101,20 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
       // (four independent partial sums: four LDS reads in flight per wave)
       auto at = [&](int mine, int r) { return smem[__builtin_amdgcn_readlane(mine, r) + lane]; };
       double mu, var;
-      if (hi - lo <= STATS_REG_ROWS) {
-        // a cell of at most 32 rows is read from LDS ONCE, every read in flight at the same
-        // time, and both passes run on registers (the two-pass loops below keep four reads
-        // in flight and read every row twice: latency-bound)
+      // a cell of at most 32 rows is read from LDS ONCE, every read in flight at the same
+      // time, and both passes run on registers (the two-pass loops below keep four reads
+      // in flight and read every row twice: latency-bound).  Three sizes, so that a
+      // ten-row cell does not pay for thirty-two guarded slots.
+      auto reg_path = [&](auto cap) {
+        constexpr int N = decltype(cap)::value;
         const int mine = mine0;
         const int m = hi - lo;
-        double x[STATS_REG_ROWS];
+        double x[N];
 #pragma unroll
-        for (int r = 0; r < STATS_REG_ROWS; ++r) x[r] = r < m ? at(mine, r) : 0.0;
+        for (int r = 0; r < N; ++r) x[r] = r < m ? at(mine, r) : 0.0;
         double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
 #pragma unroll
-        for (int r = 0; r < STATS_REG_ROWS; r += 4) {
+        for (int r = 0; r < N; r += 4) {
           m0 += x[r];
           m1 += x[r + 1];
           m2 += x[r + 2];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
         mu = ((m0 + m1) + (m2 + m3)) / cnt;
         double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
 #pragma unroll
-        for (int r = 0; r < STATS_REG_ROWS; r += 4) {
+        for (int r = 0; r < N; r += 4) {
           // (rows past the cell hold 0: their deviation is masked, not subtracted)
           const double d0 = r < m ? x[r] - mu : 0.0, d1 = r + 1 < m ? x[r + 1] - mu : 0.0;
           const double d2 = r + 2 < m ? x[r + 2] - mu : 0.0, d3 = r + 3 < m ? x[r + 3] - mu : 0.0;
@@ -131,6 +133,13 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
           q3 = fma(d3, d3, q3);
         }
         var = (q0 + q1) + (q2 + q3);
+      };
+      if (hi - lo <= 8) {
+        reg_path(std::integral_constant<int, 8>{});
+      } else if (hi - lo <= 16) {
+        reg_path(std::integral_constant<int, 16>{});
+      } else if (hi - lo <= STATS_REG_ROWS) {
+        reg_path(std::integral_constant<int, STATS_REG_ROWS>{});
       } else {
       double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
       for (int r0 = lo; r0 < hi; r0 += 64) {
