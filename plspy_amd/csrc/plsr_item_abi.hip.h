@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 using namespace plsr;
 
@@ -122,7 +123,9 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
 // ---------------------------------------------------------------------------
 namespace {
 struct FusedPlan {
-  FusedCells cells;
+  FusedCells cells;    // the cells of the statistics (caller's cells)
+  FusedCells kcells;   // the cells item_fused2_kernel walks: pieces of at most FZ_CELL_STEPS k-steps
+  bool v2;
   int MC, NT, TVX, VB, waves, nsplit, nchunk, flat, nslabm;
   int64_t nvt, nslab;
   size_t lds;
@@ -157,11 +160,42 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
     pl.cells.row_lo[c] = cell_lo[c];
     pl.cells.step_lo[c] = steps;
     pl.cells.z[c] = cell_z ? cell_z[c] : 1;
+    pl.cells.stat[c] = c;
     steps += (cell_lo[c + 1] - cell_lo[c] + 3) / 4;
   }
   pl.cells.row_lo[ncell] = cell_lo[ncell];
   pl.cells.step_lo[ncell] = steps;
   pl.cells.nkp = steps;
+  // kernel cells: every cell cut into pieces of FZ_CELL_STEPS k-steps (the cuts fall on whole
+  // k-steps, so the padded step count does not change); PLSR_K4F_RING=1 keeps the ring kernel
+  pl.v2 = getenv("PLSR_K4F_RING") == nullptr;
+  pl.kcells = pl.cells;
+  if (pl.v2) {
+    int kc = 0, ks = 0;
+    for (int c = 0; c < ncell && pl.v2; ++c) {
+      for (int lo = cell_lo[c]; lo < cell_lo[c + 1]; lo += 4 * FZ_CELL_STEPS) {
+        if (kc >= FZ_MAXCELL) {
+          pl.v2 = false;
+          break;
+        }
+        const int hi = std::min(cell_lo[c + 1], lo + 4 * FZ_CELL_STEPS);
+        pl.kcells.row_lo[kc] = lo;
+        pl.kcells.step_lo[kc] = ks;
+        pl.kcells.z[kc] = pl.cells.z[c];
+        pl.kcells.stat[kc] = c;
+        ks += (hi - lo + 3) / 4;
+        ++kc;
+      }
+    }
+    if (pl.v2) {
+      pl.kcells.ncell = kc;
+      pl.kcells.row_lo[kc] = cell_lo[ncell];
+      pl.kcells.step_lo[kc] = ks;
+      pl.kcells.nkp = ks;
+      if (ks != steps) pl.v2 = false;
+    }
+    if (!pl.v2) pl.kcells = pl.cells;
+  }
   pl.nvt = (p + pl.TVX - 1) / pl.TVX;
   pl.nsplit = (int)std::min<int64_t>(items, std::max<int64_t>(1, (1024 + pl.nvt - 1) / pl.nvt));
   // the row-offset table of a workgroup's items sits in LDS next to the X tile:
@@ -199,7 +233,7 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
 
 template <int NT, int TVX>
 int run_fused(const FusedArgs &a, const FusedPlan &pl, hipStream_t st) {
-  auto kern = item_fused_kernel<NT, TVX>;
+  auto kern = pl.v2 ? item_fused2_kernel<NT, TVX> : item_fused_kernel<NT, TVX>;
   if (pl.lds > 64 * 1024 &&
       hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
     return PLSR_ELAUNCH;
@@ -258,7 +292,7 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   ma.nz = nz;
   ma.MC = pl.MC;
   ma.row_bytes = pl.TVX * 8;
-  ma.cells = pl.cells;
+  ma.cells = pl.kcells;
   ma.frag = (double *)(w + pl.o_frag);
   ma.rowoff = (int32_t *)(w + pl.o_rowoff);
   const int64_t total = (int64_t)pl.MC * items * pl.cells.nkp * 64;
@@ -275,7 +309,8 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   a.items = items;
   a.k = k;
   a.MC = pl.MC;
-  a.cells = pl.cells;
+  a.cells = pl.kcells;
+  a.nstat = pl.cells.ncell;
   a.frag = ma.frag;
   a.rowoff = ma.rowoff;
   a.sc = sa.sc;
