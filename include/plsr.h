@@ -227,6 +227,10 @@ int plsr_apply_rows(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
  *   d_vst   : [items][k][ldv] VS^T or NULL
  *   d_rowsq : [items][ceil(k/16)*16]  sum_v VS_b[j][v]^2  or NULL
  *             (bootstrap_permutation.py:623 norms; class_functions.py:503-505 row norms)
+ *   d_sc / d_sh : NULL (the per-(item, cell, voxel) scale and shift live in the workspace), or
+ *             caller buffers [items][ncell][p]: filled by this call when stats_ready == 0,
+ *             taken as they are when stats_ready != 0 -- the multiblock bootstrap calls twice
+ *             on the same items (row norms, then projection) and computes them once
  * k <= 128, n <= 320.
  */
 size_t plsr_item_fused_workspace_bytes(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo,
@@ -235,8 +239,8 @@ size_t plsr_item_fused_workspace_bytes(int32_t n, int32_t nz, int32_t k, const i
 int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src,
                     int32_t nz, const int32_t *cell_lo, const int32_t *cell_z, int32_t ncell,
                     const double *d_rows, int32_t items, int32_t k, const double *d_ref, double *d_S1,
-                    double *d_S2, double *d_vst, int64_t ldv, double *d_rowsq, void *d_work,
-                    size_t work_bytes, void *stream);
+                    double *d_S2, double *d_vst, int64_t ldv, double *d_rowsq, double *d_sc,
+                    double *d_sh, int32_t stats_ready, void *d_work, size_t work_bytes, void *stream);
 
 /*
  * Multiblock operator rows for plsr_item_fused, formed on the device from the

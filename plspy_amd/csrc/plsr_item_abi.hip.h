@@ -255,8 +255,10 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
                                int32_t nz, const int32_t *cell_lo, const int32_t *cell_z, int32_t ncell,
                                const double *d_rows, int32_t items, int32_t k, const double *d_ref,
                                double *d_S1, double *d_S2, double *d_vst, int64_t ldv, double *d_rowsq,
-                               void *d_work, size_t work_bytes, void *stream) {
+                               double *d_sc, double *d_sh, int32_t stats_ready, void *d_work,
+                               size_t work_bytes, void *stream) {
   if (!d_X || !d_src || !d_rows || !d_work || !cell_lo || !cell_z || ldx < p) return PLSR_EINVAL;
+  if ((d_sc == nullptr) != (d_sh == nullptr) || (stats_ready && !d_sc)) return PLSR_EINVAL;
   if ((d_S1 == nullptr) != (d_S2 == nullptr) || (d_vst && ldv < p)) return PLSR_EINVAL;
   FusedPlan pl;
   if (!fused_plan(n, nz, k, cell_lo, cell_z, ncell, items, p, d_S1 != nullptr, d_rowsq != nullptr, pl))
@@ -274,15 +276,16 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   sa.items = items;
   sa.src = d_src;
   sa.cells = pl.cells;
-  sa.sc = (double *)(w + pl.o_sc);
-  sa.sh = (double *)(w + pl.o_sh);
+  sa.sc = d_sc ? d_sc : (double *)(w + pl.o_sc);
+  sa.sh = d_sh ? d_sh : (double *)(w + pl.o_sh);
   const size_t lds_stats = (size_t)n * TV * sizeof(double);
   if (lds_stats > 64 * 1024 &&
       hipFuncSetAttribute((const void *)item_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_stats) != hipSuccess)
     return PLSR_ELAUNCH;
-  hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)((p + TV - 1) / TV), (unsigned)pl.nsplit), dim3(256),
-                     lds_stats, st, sa);
+  if (!stats_ready)
+    hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)((p + TV - 1) / TV), (unsigned)pl.nsplit), dim3(256),
+                       lds_stats, st, sa);
 
   MetaArgs ma;
   ma.rows = d_rows;

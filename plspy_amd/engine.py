@@ -326,10 +326,12 @@ class ProjectionEngine:
 
     # -- K4 / K5: bootstrap with per-resample matrices --------------------------
     def item_fused(self, src, cell_lo, cell_z, rows, ref=None, S1=None, S2=None, want_vst=False,
-                   want_rowsq=False):
+                   want_rowsq=False, stats=None):
         """K4f: VS_b = rows_b @ Z_b for every item without materialising Z_b
         (Z_b = X[src_b] z-scored within the cells flagged in cell_z).
         rows (items, k, nz).  S1 / S2 (p, k) are accumulated into when given.
+        stats: None, or a dict shared by several calls on the SAME src / cells: the first call
+        stores the per-(item, cell, voxel) scale and shift in it, later calls reuse them.
         Returns (vst (items, k, p) or None, rowsq (items, k) or None)."""
         d_src = self.dev(src, torch.int32)
         d_rows = self.dev(rows)
@@ -347,9 +349,18 @@ class ProjectionEngine:
         vst = torch.empty((items, k, self.p), dtype=torch.float64, device=self.device) if want_vst else None
         k16 = (k + 15) // 16 * 16
         rowsq = torch.empty((items, k16), dtype=torch.float64, device=self.device) if want_rowsq else None
+        sc = sh = None
+        ready = 0
+        if stats is not None:
+            if "sc" in stats:
+                sc, sh, ready = stats["sc"], stats["sh"], 1
+            else:
+                sc = stats["sc"] = torch.empty((items, ncell, self.p), dtype=torch.float64, device=self.device)
+                sh = stats["sh"] = torch.empty_like(sc)
         _lib.check(self.lib.plsr_item_fused(
             _ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_src), nz, lo, zf, ncell, _ptr(d_rows),
-            items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p, _ptr(rowsq), _ptr(work), need,
+            items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p, _ptr(rowsq), _ptr(sc), _ptr(sh), ready,
+            _ptr(work), need,
             _stream()), "plsr_item_fused")
         return vst, (rowsq[:, :k] if want_rowsq else None)
 
@@ -406,7 +417,8 @@ class ProjectionEngine:
                 # norms over all voxels of the un-normalised rows, K4f in norms-only mode
                 raw = np.ascontiguousarray(raw_rows_fn(lo, hi), dtype=np.float64)
                 d_raw = self.dev(raw)
-                _, rsq = self.item_fused(d_src, cell_lo, cell_z, d_raw, want_rowsq=True)
+                stats = {}                       # both passes run on the same items: statistics once
+                _, rsq = self.item_fused(d_src, cell_lo, cell_z, d_raw, want_rowsq=True, stats=stats)
                 if project_on is None:
                     rownorm = np.sqrt(rsq.cpu().numpy())
             if raw_rows_fn is not None and project_on is not None:
@@ -419,7 +431,7 @@ class ProjectionEngine:
             else:
                 ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
             vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
-                                       want_rowsq=True)
+                                       want_rowsq=True, stats=stats if raw_rows_fn is not None else None)
             nsq[lo:hi] = rsq
             need2 = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
             if need2 == 0:
