@@ -260,6 +260,7 @@ int plsr_scale_project_rows(const double *d_raw, const double *d_rowsq, int64_t 
  * is X[d_src[b]] z-scored within the cells, never stored; G_b = (rows_b Z_b)(rows_b Z_b)^T.
  *   d_src : [items][nz] int32, cell_lo / cell_z : HOST arrays as in plsr_item_fused,
  *   d_frag: plsr_ops_pack_rows(items, m, nz)
+ * nz <= 256 (the kernel keeps an item's source-row and cell tables in registers), m <= 96.
  */
 size_t plsr_gram_fused_workspace_bytes(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo,
                                        int32_t ncell, int32_t items, int64_t p);
