@@ -70,30 +70,39 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
     }
 
   double pv[NV], px[NX];
+  // Unconditional loads from clamped addresses (a load under a branch costs a branch per load,
+  // a select on the loaded value would make the fetch wait for its own data); what does not
+  // exist -- voxels past p, tiles past the chunk, rows past k / n -- is zeroed when the tile is
+  // parked (pinv remembers the fetched tile's voxel validity).
+  bool pinv = false;
   auto fetch = [&](int64_t vt) {
     const int64_t vv = vt * LV_T + svox;
-    const bool inv = vv < A.p && vt < t_hi;
+    pinv = vv < A.p && vt < t_hi;
+    const int64_t vc = min(vv, A.p - 1);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-      const int rr = q * RPP + srow;                        // row of the stacked [IG][MC*16] tile
-      const int ig = rr / (MC * 16), row = rr % (MC * 16);
+      const int rr = min(q * RPP + srow, IG * MC * 16 - 1);  // row of the stacked [IG][MC*16] tile
+      const int ig = rr / (MC * 16), row = min(rr % (MC * 16), A.k - 1);
       const int item = min(item0 + ig, A.items - 1);        // a short last group recomputes the last item
-      pv[q] = (inv && rr < IG * MC * 16 && row < A.k) ? A.vst[((int64_t)item * A.k + row) * A.ldv + vv] : 0.0;
+      pv[q] = A.vst[((int64_t)item * A.k + row) * A.ldv + vc];
     }
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
-      const int row = q * RPP + srow;
-      px[q] = (inv && row < A.n) ? A.X[(int64_t)row * A.ldx + vv] : 0.0;
+      const int row = min(q * RPP + srow, A.n - 1);
+      px[q] = A.X[(int64_t)row * A.ldx + vc];
     }
   };
   auto park = [&]() {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int rr = q * RPP + srow;
-      if (rr < IG * MC * 16) Vs[rr * LV_LD + svox] = pv[q];
+      if (rr < IG * MC * 16) Vs[rr * LV_LD + svox] = (pinv && rr % (MC * 16) < A.k) ? pv[q] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < NX; ++q) Xs[(q * RPP + srow) * LV_LD + svox] = px[q];
+    for (int q = 0; q < NX; ++q) {
+      const int row = q * RPP + srow;
+      Xs[row * LV_LD + svox] = (pinv && row < A.n) ? px[q] : 0.0;
+    }
   };
 
   fetch(t_lo);
@@ -102,24 +111,36 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
     park();
     __syncthreads();
     fetch(vt + 1);                    // in flight during the MFMAs below
+    // k-steps of the tile, software-pipelined: the LDS operands of step s + 1 are read into
+    // the other of two register sets before the MFMAs of step s are issued
+    auto ldk = [&](int s, double (&av)[IG][MC], double (&bv)[NI]) {
 #pragma unroll
-    for (int s = 0; s < LV_T / 4; ++s) {
-      double b[NI];
+      for (int ni = 0; ni < NI; ++ni) bv[ni] = Xs[((wave * NI + ni) * 16 + col) * LV_LD + 4 * s + g];   // B[k = v][n = i]
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int it = wave * NI + ni;                          // this wave's tiles of data rows
-        b[ni] = Xs[(it * 16 + col) * LV_LD + 4 * s + g];            // B[k = v][n = i]
-      }
+      for (int ig = 0; ig < IG; ++ig)
 #pragma unroll
-      for (int ig = 0; ig < IG; ++ig) {
+        for (int mc = 0; mc < MC; ++mc) av[ig][mc] = Vs[((ig * MC + mc) * 16 + col) * LV_LD + 4 * s + g];   // A[m = j][k = v]
+    };
+    auto mmk = [&](double (&av)[IG][MC], double (&bv)[NI]) {
+#pragma unroll
+      for (int ig = 0; ig < IG; ++ig)
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc) {
-          const double a = Vs[((ig * MC + mc) * 16 + col) * LV_LD + 4 * s + g];   // A[m = j][k = v]
-          if (want_nsq) nsq[ig][mc] = fma(a, a, nsq[ig][mc]);
+          if (want_nsq) nsq[ig][mc] = fma(av[ig][mc], av[ig][mc], nsq[ig][mc]);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[ig][mc][ni] = mfma_f64(a, b[ni], acc[ig][mc][ni]);
+          for (int ni = 0; ni < NI; ++ni) acc[ig][mc][ni] = mfma_f64(av[ig][mc], bv[ni], acc[ig][mc][ni]);
         }
-      }
+    };
+    double a0[IG][MC], a1[IG][MC], b0[NI], b1[NI];
+    ldk(0, a0, b0);
+#pragma unroll
+    for (int s = 0; s < LV_T / 4; s += 2) {
+      ldk(s + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mmk(a0, b0);
+      if (s + 2 < LV_T / 4) ldk(s + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mmk(a1, b1);
     }
   }
 

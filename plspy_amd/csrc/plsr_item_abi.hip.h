@@ -17,7 +17,7 @@ int launch_ok() { return hipGetLastError() == hipSuccess ? PLSR_OK : PLSR_ELAUNC
 // items per workgroup of the latent kernel: bounded by the accumulator tiles
 // (IG * MC * NI x 8 VGPRs) that fit without scratch
 constexpr int latent_group_cap(int mc, int ni) {
-  const int c = 12 / (mc * ni);
+  const int c = 10 / (mc * ni);      // (12 let the 4 x 1 x 3, 2 x 2 x 3 and 3 x 2 x 2 instances spill 24-350 B per lane)
   return c < 1 ? 1 : (c > 3 ? 3 : c);
 }
 
