@@ -388,7 +388,7 @@ class _ResampleTestPLS(ResampleTest):
         conf_int = (Tvsc_orig - half, Tvsc_orig + half)               # :717
 
         # left_sv_sampled[i] = permuted_i @ V = W P_i (X V)   (:617, :631) -- p-free
-        XV = np.asarray(self._X, dtype=float) @ V
+        XV = eng.latents(V)                                           # X @ V on the device (K5, one item)
         left = self._W @ XV[inds]                                     # (c,r)(b,r,k) -> b,c,k
         debug = {
             "left_sv_sampled": left,

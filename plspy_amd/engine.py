@@ -255,6 +255,25 @@ class ProjectionEngine:
                                             _ptr(out), self.p, _stream()), "plsr_apply_rows")
         return out
 
+    def latents(self, V, rows=None):
+        """X @ V (n x k) for a host matrix V (p x k): the observed latent scores
+        (class_functions.py:165-182, pls_classes.py:263) and the bootstrap's
+        left_sv_sampled base `X @ V` (bootstrap_permutation.py:617), through K5 with a single
+        item.  On the host this product reads all of X (5 ms at config 2, 40 ms at config 5)."""
+        V = np.asarray(V, dtype=np.float64)
+        if V.ndim != 2 or V.shape[0] != self.p:
+            raise ValueError(f"V must be ({self.p}, k)")
+        k = V.shape[1]
+        need = self.lib.plsr_latent_workspace_bytes(self.n, k, 1, self.p)
+        if need == 0:
+            raise _lib.PlsrError(f"plsr_latent: unsupported shape n={self.n} k={k}")
+        vt = self.dev(V).t().contiguous()                  # (k, p): a layout copy on the device
+        Zt = torch.empty((1, k, self.n), dtype=torch.float64, device=self.device)
+        work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(vt), self.p, 1, k,
+                                        _ptr(Zt), _ptr(None), _ptr(work), need, _stream()), "plsr_latent")
+        return np.ascontiguousarray(Zt[0].t().cpu().numpy())
+
     # -- K2: Gram / thin SVD -------------------------------------------------
     def gram_phase(self, rows, gather=None):
         """rows: (S, m, n') operator rows (NumPy).  Returns the (S, mm, mm) Grams

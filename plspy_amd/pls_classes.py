@@ -139,7 +139,7 @@ class _MeanCentreTaskPLS(PLSBase):
         blocks = engine.apply_operator(np.vstack((Wm, W))).cpu().numpy()
         self.X_means, self.X_mc = blocks[:len(Wm)], blocks[len(Wm):]
         self.U, self.s, self.V = engine.thin_svd(W)
-        self.X_latent = np.dot(self.X, self.V)
+        self.X_latent = engine.latents(self.V)                       # X @ V on the device (K5)
         Tvsc_orig = Wm @ self.X_latent
 
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
@@ -202,7 +202,7 @@ class _RegularBehaviourPLS(PLSBase):
         A = cf.corr_operator(cf.zscore_cells(np.asarray(Y, dtype=float), bounds), bounds)
         self.R = eng_z.apply_operator(A).cpu().numpy()
         self.U, self.s, self.V = eng_z.thin_svd(A)                     # :574
-        self.X_latent = np.dot(self.X, self.V)
+        self.X_latent = engine.latents(self.V)                         # X @ V on the device (K5)
         self.Y_latent = cf.compute_Y_latents(self.Y, self.U, co)
         self.lvcorrs = cf.compute_corr_small(self.X_latent, self.Y, co)   # :581-583
 
@@ -289,8 +289,8 @@ class _MultiblockPLS(PLSBase):
         self.U, self.s, self.V = eng_c.thin_svd(normed)              # :1456
 
         V_normed = cf.normalize(self.V)
-        T_X_latent = np.dot(self.X, V_normed)                        # :1460-1461
-        B_X_latent = np.dot(self.Xbscan, self.V)                     # :1464
+        T_X_latent = engine.latents(V_normed)                        # :1460-1461, on the device (K5)
+        B_X_latent = engine.latents(self.V)[mask]                    # :1464  Xbscan @ V = (X @ V)[bscan rows]
         self.X_latent = np.vstack((T_X_latent, B_X_latent))
         self.usc, self.Tusc, self.Busc = self.X_latent, T_X_latent, B_X_latent
         Tu, Bu = cf.split_Tu_Bu(self.U, num_conditions, self.Y.shape[1], ng, nbs)
@@ -376,7 +376,7 @@ class _ContrastTaskPLS(PLSBase):
         self.R = engine.apply_operator(Wm).cpu().numpy()                         # :853
         self.U, self.s, self.V = _contrast_decomposition(engine, Wm, self.contrasts)   # :854-856
         self.lvintercorrs = self.V.T @ self.V
-        self.X_latent = np.dot(self.X, cf.normalize(self.V))
+        self.X_latent = engine.latents(cf.normalize(self.V))
         Tvsc_orig = Wm @ self.X_latent
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
             self.pls_alg, self.X, None, self.U, self.s, self.V, self.cond_order, self.mctype,
@@ -418,7 +418,7 @@ class _ContrastBehaviourPLS(PLSBase):
         self.R = eng_z.apply_operator(A).cpu().numpy()
         self.U, self.s, self.V = _contrast_decomposition(eng_z, A, self.contrasts)
         self.lvintercorrs = self.V.T @ self.V
-        self.X_latent = np.dot(self.X, self.V)
+        self.X_latent = engine.latents(self.V)
         self.Y_latent = cf.compute_Y_latents(self.Y, self.U, co)
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
             self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, None,
@@ -483,8 +483,8 @@ class _ContrastMultiblockPLS(PLSBase):
         self.multiblock = eng_c.apply_operator(normed).cpu().numpy()
         self.U, self.s, self.V = _contrast_decomposition(eng_c, normed, self.contrasts)
 
-        T_X_latent = np.dot(self.X, cf.normalize(self.V))
-        B_X_latent = np.dot(self.Xbscan, self.V)
+        T_X_latent = engine.latents(cf.normalize(self.V))
+        B_X_latent = engine.latents(self.V)[mask]
         self.X_latent = np.vstack((T_X_latent, B_X_latent))
         Tu, Bu = cf.split_Tu_Bu(self.U, num_conditions, self.Y.shape[1], ng, nbs)
         Tusc = cf.get_Tusc(Tu, num_conditions, co)
