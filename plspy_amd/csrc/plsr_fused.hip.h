@@ -177,10 +177,13 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
       }
       var = (q0 + q1) + (q2 + q3);
       }
-      const double sd = sqrt(var / cnt);
-      // scipy.stats.zscore's constant-slice rule followed by nan_to_num -> 0
-      const bool dead = !(sd > 2.220446049250313e-16 * fabs(mu));
-      sc = dead ? 0.0 : 1.0 / (sd * sqrt(cnt));
+      // scipy.stats.zscore's constant-slice rule (sd <= eps |mu|) followed by nan_to_num -> 0,
+      // and sc = 1 / (sd sqrt(n_c)) with sd = sqrt(var / n_c), i.e. 1 / sqrt(var): one rsqrt
+      // instead of a division, two square roots and another division (this kernel is bound by
+      // the latency of its dependent fp64 arithmetic)
+      const double em = 2.220446049250313e-16 * fabs(mu);
+      const bool dead = !(var > cnt * em * em);
+      sc = dead ? 0.0 : rsqrt(var);
       sh = dead ? 0.0 : -mu * sc;
     }
     if (v < A.p) {
