@@ -77,6 +77,8 @@ def test_full_pls_call(name):
     assert_close(res.U[:, live] * sign, fx["V"][:, live], 1e-8, 1e-10, "V (voxel saliences)")
     assert_close(res.X_mc, fx["X_mc"], 1e-10, 1e-12, "X_mc")
     assert_close(res.X_means, fx["X_means"], 1e-10, 1e-12, "X_means")
+    # observed latent scores X @ V (engine.latents: K5 with a single item)
+    assert_close(res.X_latent[:, live] * sign, fx["X_latent"][:, live], 1e-9, 1e-10, "X_latent")
     rt = res.resample_tests
     assert_close(rt.perm_debug_dict["s_list"][:, live], fx["s_list"][:, live], 1e-9, 1e-11, "s_list")
     n1 = fx["nperm"] + 1

@@ -167,3 +167,17 @@ def test_apply_rows_random_shapes():
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max(), err_msg=f"{n} {p} {m}")
     with pytest.raises(ValueError):
         eng.apply_operator(np.zeros((2, 5)))
+
+
+def test_latents_random_shapes():
+    """engine.latents (observed X @ V through K5 with one item) against NumPy: n on both sides of
+    the 4-wave / 8-wave switch, k up to the kernel's 64, voxel counts off the 32-voxel tile."""
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(21)
+    for n, p, k in [(5, 1, 1), (60, 257, 6), (64, 1000, 17), (65, 333, 48), (120, 2001, 38), (200, 515, 64),
+                    (256, 96, 12)]:
+        X = rs.randn(n, p)
+        V = rs.randn(p, k)
+        got = ProjectionEngine(X).latents(V)
+        want = X @ V
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11 * np.abs(want).max(), err_msg=f"{n} {p} {k}")
