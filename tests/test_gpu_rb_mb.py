@@ -52,6 +52,7 @@ def test_rb_observed_and_perm(name):
     assert_close(res.V[:, live] * sign, fx["U"][:, live], 1e-7, 1e-9, "U")
     assert_close(res.U[:, live] * sign, fx["V"][:, live], 1e-7, 1e-9, "V")
     assert_close(res.lvcorrs[:, live] * sign, fx["lvcorrs"][:, live], 1e-7, 1e-9, "lvcorrs")
+    assert_close(res.X_latent[:, live] * sign, fx["X_latent"][:, live], 1e-7, 1e-9, "X_latent")
     rt = res.resample_tests
     assert_close(rt.perm_debug_dict["s_list"][:, live], fx["s_list"][:, live], 1e-9, 1e-11, "s_list")
     n1 = fx["nperm"] + 1
