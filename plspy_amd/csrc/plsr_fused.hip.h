@@ -42,6 +42,7 @@ constexpr int FZ_MAXCELL = 64;
 #endif
 constexpr int FZ_CELL_STEPS = 8;   // k-steps per cell of item_fused2_kernel (longer cells are split by the host)
 constexpr int FZ_RING = PLSR_FZ_RING;   // k-steps the operator-fragment ring of item_fused_kernel runs ahead (4 or 8; 8 measured 10 % slower at config 3: more scratch)
+constexpr int STATS_WAVES = 8;  // waves per workgroup of the statistics kernel
 constexpr int STATS_REG_ROWS = 32;   // cells up to this many rows take the statistics kernel's register path
 
 struct FusedCells {
@@ -62,14 +63,17 @@ struct StatsArgs {
   double *sc, *sh;                     // [items][ncell][p]
 };
 
-__global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
+__global__ __launch_bounds__(512) void item_stats_kernel(StatsArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t v0 = (int64_t)blockIdx.x * TV;
   const int64_t v = v0 + lane;
-  for (int row = wave; row < A.n; row += WAVES)
+  // eight waves per workgroup (STATS_WAVES): the kernel is bound by the latency of dependent
+  // fp64 arithmetic, and the X tile allows two workgroups per CU only -- four waves per SIMD
+  const int NW = blockDim.x >> 6;
+  for (int row = wave; row < A.n; row += NW)
     smem[row * TV + lane] = v < A.p ? A.X[(int64_t)row * A.ldx + v] : 0.0;
   __syncthreads();
   const int per = (A.items + gridDim.y - 1) / gridDim.y;
@@ -87,9 +91,9 @@ __global__ __launch_bounds__(256) void item_stats_kernel(StatsArgs A) {
     return lane < hi2 - lo2 ? A.src[(int64_t)item2 * A.nz + lo2 + lane] * TV : 0;
   };
   int mine_next = cell_rows(it_lo * ncell + wave);
-  for (int e = it_lo * ncell + wave; e < it_hi * ncell; e += WAVES) {
+  for (int e = it_lo * ncell + wave; e < it_hi * ncell; e += NW) {
     const int mine0 = mine_next;
-    mine_next = cell_rows(e + WAVES);
+    mine_next = cell_rows(e + NW);
     const int item = e / ncell;
     const int c = e - item * ncell;
     const int lo = A.cells.row_lo[c], hi = A.cells.row_lo[c + 1];

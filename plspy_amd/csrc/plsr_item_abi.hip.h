@@ -284,8 +284,8 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
                           (int)lds_stats) != hipSuccess)
     return PLSR_ELAUNCH;
   if (!stats_ready)
-    hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)((p + TV - 1) / TV), (unsigned)pl.nsplit), dim3(256),
-                       lds_stats, st, sa);
+    hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)((p + TV - 1) / TV), (unsigned)pl.nsplit),
+                       dim3(64 * STATS_WAVES), lds_stats, st, sa);
 
   MetaArgs ma;
   ma.rows = d_rows;
@@ -435,7 +435,8 @@ extern "C" int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_
     return PLSR_ELAUNCH;
   const int64_t nvt = (p + TV - 1) / TV;
   const int nsplit = (int)std::min<int64_t>(items, std::max<int64_t>(1, (1024 + nvt - 1) / nvt));
-  hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)nvt, (unsigned)nsplit), dim3(256), lds_stats, st, sa);
+  hipLaunchKernelGGL(item_stats_kernel, dim3((unsigned)nvt, (unsigned)nsplit), dim3(64 * STATS_WAVES), lds_stats, st,
+                     sa);
   int32_t *rowcell = (int32_t *)(w + pl.o_cell);
   hipLaunchKernelGGL(rowcell_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, pl.cells, nz, rowcell);
 
