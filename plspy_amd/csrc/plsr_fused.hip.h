@@ -18,7 +18,7 @@
 //   item_meta_kernel    operator fragments (MFMA A operand, cells padded to
 //                       whole k-steps) and the LDS row offset of every (k-step,
 //                       lane group)
-//   item_fused_kernel   B operand = LDS row gathered through the offset table,
+//   item_fused2_kernel  B operand = LDS row gathered through the offset table,
 //                       z-scored on the fly (one FMA), MFMA against the
 //                       operator fragments streamed from L2 through a register
 //                       ring.  One wave = one 16-row tile of latent variables x
@@ -36,21 +36,18 @@
 
 namespace plsr {
 
-constexpr int FZ_MAXCELL = 64;
-#ifndef PLSR_FZ_RING
-#define PLSR_FZ_RING 4
-#endif
+constexpr int FZ_MAXCELL = 64;      // cells of a caller
+constexpr int FZ_MAXPIECE = 80;     // pieces of at most FZ_CELL_STEPS k-steps they are cut into (nz <= 320: <= 64 + 10)
 constexpr int FZ_CELL_STEPS = 8;   // k-steps per cell of item_fused2_kernel (longer cells are split by the host)
-constexpr int FZ_RING = PLSR_FZ_RING;   // k-steps the operator-fragment ring of item_fused_kernel runs ahead (4 or 8; 8 measured 10 % slower at config 3: more scratch)
 constexpr int STATS_WAVES = 8;  // waves per workgroup of the statistics kernel
 constexpr int STATS_REG_ROWS = 32;   // cells up to this many rows take the statistics kernel's register path
 
 struct FusedCells {
   int32_t ncell, nkp;                  // cells, padded k-steps per item
-  int32_t row_lo[FZ_MAXCELL + 1];      // output-row range of every cell
-  int32_t step_lo[FZ_MAXCELL + 1];     // k-step range of every cell
-  int32_t z[FZ_MAXCELL];               // 1 = z-score, 0 = copy
-  int32_t stat[FZ_MAXCELL];            // cell of the scale / shift arrays (cells split for item_fused_kernel share one)
+  int32_t row_lo[FZ_MAXPIECE + 1];      // output-row range of every cell
+  int32_t step_lo[FZ_MAXPIECE + 1];     // k-step range of every cell
+  int32_t z[FZ_MAXPIECE];              // 1 = z-score, 0 = copy
+  int32_t stat[FZ_MAXPIECE];           // cell of the scale / shift arrays (pieces of one cell share it)
 };
 
 // ---------------------------------------------------------------------------
@@ -256,252 +253,10 @@ struct FusedArgs {
 // tile-major order: a wave then works on one tile for a run of items and possibly
 // on the next tile for another run ("segments"); a tile's moment sums come from
 // two waves and go to two partial slabs (zero-filled by the host, merged later).
-template <int NT, int TVX>
-__global__ __launch_bounds__(512) void item_fused_kernel(FusedArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int VB = TVX / (16 * NT);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int vb = A.flat ? 0 : wave / A.MC;
-  const int col = lane & 15;
-  const int g = lane >> 4;
-  const int64_t v0 = (int64_t)blockIdx.x * TVX;
-
-  // ---- the whole X[:, tile] stays in LDS for the life of the workgroup ----
-  for (int e = tid; e < A.n * TVX; e += blockDim.x) {
-    const int row = e / TVX;
-    const int64_t v = v0 + (e % TVX);
-    smem[e] = v < A.p ? A.X[(int64_t)row * A.ldx + v] : 0.0;
-  }
-  const char *Xb = (const char *)smem + ((vb * NT) * 16 + col) * 8;   // + rowoff + nt*128
-
-  const int per = (A.items + gridDim.y - 1) / gridDim.y;
-  const int it_lo = blockIdx.y * per;
-  const int it_hi = min(A.items, it_lo + per);
-  const int nkp = A.cells.nkp;
-  const int ncell = A.cells.ncell;
-  // ---- and the row-offset table of this workgroup's items (a second vector
-  // stream from L2 next to the fragments stalled the vector L1) ----
-  int32_t *tbl = (int32_t *)(smem + (size_t)A.n * TVX);
-  {
-    const int cnt = (max(it_hi - it_lo, 0) * nkp + 8) * 4;        // + 8 steps of look-ahead padding
-    const int32_t *src = A.rowoff + (size_t)it_lo * nkp * 4;      // (the buffer carries the same padding)
-    for (int e = tid; e < cnt; e += blockDim.x) tbl[e] = src[e];
-  }
-  __syncthreads();
-  if (it_lo >= it_hi) return;
-
-  // voxel of tile nt = vbase + 16 nt (kept as one register, not NT of them)
-  const int64_t vbase = v0 + vb * NT * 16 + col;
-  struct {
-    int64_t b;
-    __device__ int64_t operator[](int nt) const { return b + 16 * nt; }
-  } vox{vbase};
-
-  // plain sums over this workgroup's items; the shift by the observed VS is
-  // applied when the partials are merged (moment_unshift_kernel) -- keeping the
-  // shift in registers here would push the NT = 4 instance into scratch
-  double s1[NT][4], s2[NT][4];
-  const bool moments = A.S1 != nullptr;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s1[nt][r] = 0.0;
-      s2[nt][r] = 0.0;
-    }
-
-  // this wave's segments: (tile of latent variables, run of items)
-  const int cnt = it_hi - it_lo;
-  int seg_mc[2], seg_a[2], seg_b[2], nseg = 1;
-  if (!A.flat) {
-    seg_mc[0] = wave % A.MC;
-    seg_a[0] = it_lo;
-    seg_b[0] = it_hi;
-  } else {
-    const int nw = blockDim.x >> 6;
-    const int U = A.MC * cnt;
-    const int u0 = (int)((int64_t)wave * U / nw), u1 = (int)((int64_t)(wave + 1) * U / nw);
-    const int m0 = u0 / cnt;
-    seg_mc[0] = m0;
-    seg_a[0] = it_lo + (u0 - m0 * cnt);
-    seg_b[0] = it_lo + min(cnt, u1 - m0 * cnt);
-    if (u1 > (m0 + 1) * cnt) {
-      nseg = 2;
-      seg_mc[1] = m0 + 1;
-      seg_a[1] = it_lo;
-      seg_b[1] = it_lo + (u1 - (m0 + 1) * cnt);
-    }
-    if (u0 >= u1) nseg = 0;
-  }
-
-  for (int sg = 0; sg < nseg; ++sg) {
-  const int mc = seg_mc[sg];
-  const int sa = seg_a[sg], sb = seg_b[sg];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s1[nt][r] = 0.0;
-      s2[nt][r] = 0.0;
-    }
-
-  // Stream of k-steps over (item, cell, step): fragments and row offsets are
-  // contiguous per wave, so the 4-deep register rings run on across cell and
-  // item boundaries.  The k-loops hold no memory operation besides the rings
-  // (the scale / shift of a cell are prefetched one cell ahead, between loops).
-  const double *fp = A.frag + ((size_t)mc * A.items * nkp + (size_t)it_lo * nkp) * 64 + lane;
-  const int32_t *rp = tbl + g;           // LDS: byte offset of the row of (step, lane group)
-  int64_t pos = (int64_t)(sa - it_lo) * nkp;    // stream position of the current cell's first step
-  double ra[FZ_RING];
-#pragma unroll
-  for (int u = 0; u < FZ_RING; ++u) ra[u] = fp[(size_t)(pos + u) * 64];
-  double bn[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + rp[pos * 4] + nt * 128);
-  int ro1 = rp[(pos + 1) * 4];           // rows of the next step
-
-  // Unconditional loads (clamped addresses): a select on the loaded value would
-  // make the prefetch wait for its own data.  Lanes past p read voxel p-1 and
-  // are masked where results leave the kernel.
-  auto load_cell = [&](int item, int c, double (&sc)[NT], double (&sh)[NT]) {
-    const int64_t base = ((int64_t)min(item, it_hi - 1) * A.nstat + A.cells.stat[c]) * A.p;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int64_t vc = min(vox[nt], A.p - 1);
-      sc[nt] = A.sc[base + vc];
-      sh[nt] = A.sh[base + vc];
-    }
-  };
-
-  double sc[NT], sh[NT], scn[NT], shn[NT];
-  load_cell(sa, 0, scn, shn);
-
-  f64x4 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
-
-  int phase = 0;                         // ring slot of the current cell's first step
-  for (int item = sa; item < sb; ++item) {
-    for (int c = 0; c < ncell; ++c) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        sc[nt] = scn[nt];
-        sh[nt] = shn[nt];
-      }
-      {
-        const bool last = c + 1 == ncell;
-        load_cell(last ? item + 1 : item, last ? 0 : c + 1, scn, shn);
-      }
-      const int ns = A.cells.step_lo[c + 1] - A.cells.step_lo[c];
-      const double *fq = fp + (size_t)pos * 64;
-      const int32_t *rq = rp + pos * 4;
-
-      // one k-step: uses fragment ring slot u (refilled four steps ahead), reads the
-      // raw rows of the next step and the row offsets of the one after (both LDS)
-      auto step = [&](int sidx, int u, int) {
-        double z[NT];
-#pragma unroll
-#if PLSR_ABLATE & 512
-        for (int nt = 0; nt < NT; ++nt) z[nt] = bn[nt];
-#else
-        for (int nt = 0; nt < NT; ++nt) z[nt] = fma(bn[nt], sc[nt], sh[nt]);
-#endif
-        const int ron = ro1;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const double *)(Xb + ron + nt * 128);
-        ro1 = rq[(sidx + 2) * 4];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f64(ra[u], z[nt], acc[nt]);
-        ra[u] = fq[(size_t)(sidx + FZ_RING) * 64];
-      };
-
-      // A cell rarely has a multiple of four steps, so the ring slot of its first
-      // step ("phase") moves from cell to cell.  Rotating the ring registers would
-      // need every outstanding load back (s_waitcnt vmcnt(0) once per cell);
-      // instead the loop exists in four variants with static slot numbers.
-      auto run = [&](auto ph) {
-        constexpr int P = decltype(ph)::value;
-        constexpr int M = FZ_RING - 1;
-        int s = 0;
-        for (; s + FZ_RING <= ns; s += FZ_RING) {
-#pragma unroll
-          for (int u = 0; u < FZ_RING; ++u) step(s + u, (P + u) & M, (P + u + 1) & M);
-        }
-        const int rem = ns & M;
-#pragma unroll
-        for (int u = 0; u < M; ++u)
-          if (u < rem) step(s + u, (P + u) & M, (P + u + 1) & M);
-      };
-      switch (phase) {
-        case 0: run(std::integral_constant<int, 0>{}); break;
-        case 1: run(std::integral_constant<int, 1 % FZ_RING>{}); break;
-        case 2: run(std::integral_constant<int, 2 % FZ_RING>{}); break;
-        case 3: run(std::integral_constant<int, 3 % FZ_RING>{}); break;
-        case 4: run(std::integral_constant<int, 4 % FZ_RING>{}); break;
-        case 5: run(std::integral_constant<int, 5 % FZ_RING>{}); break;
-        case 6: run(std::integral_constant<int, 6 % FZ_RING>{}); break;
-        default: run(std::integral_constant<int, 7 % FZ_RING>{}); break;
-      }
-      phase = (phase + ns) & (FZ_RING - 1);
-      pos += ns;
-    }
-
-    // ---- item done: acc[nt][r] = VS[j = 16 mc + g + 4 r][voxel nt] ----
-    double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = mc * 16 + g + 4 * r;
-        const double val = acc[nt][r];
-        if (moments) {
-          s1[nt][r] += val;
-          s2[nt][r] = fma(val, val, s2[nt][r]);
-        }
-        if (vox[nt] < A.p) q[r] = fma(val, val, q[r]);
-        if (A.vst != nullptr && j < A.k && vox[nt] < A.p)
-          A.vst[((int64_t)item * A.k + j) * A.ldv + vox[nt]] = val;
-        acc[nt][r] = 0.0;
-      }
-    if (A.rowsq_part != nullptr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double x = q[r];
-        x += __shfl_xor(x, 1);
-        x += __shfl_xor(x, 2);
-        x += __shfl_xor(x, 4);
-        x += __shfl_xor(x, 8);
-        if (col == 0)
-          A.rowsq_part[(((int64_t)blockIdx.x * VB + vb) * A.items + item) * (A.MC * 16) + mc * 16 + g + 4 * r] = x;
-      }
-    }
-  }
-
-  if (moments) {
-    // flat mode: the wave that starts a tile's items writes slab 0, the one that ends them slab 1
-    const int slab = A.flat ? 2 * blockIdx.y + (sa == it_lo ? 0 : 1) : blockIdx.y;
-    double *o1 = A.S1 + (int64_t)slab * A.p * A.k;
-    double *o2 = A.S2 + (int64_t)slab * A.p * A.k;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = mc * 16 + g + 4 * r;
-        if (j < A.k && vox[nt] < A.p) {
-          o1[vox[nt] * A.k + j] = s1[nt][r];
-          o2[vox[nt] * A.k + j] = s2[nt][r];
-        }
-      }
-  }
-  }   // segments
-}
-
-// item_fused2_kernel: item_fused_kernel with the operator fragments of a WHOLE CELL
-// prefetched one cell ahead (fc / fn, static register indices) instead of the 4-deep ring:
-// the ring's slot phase moved from cell to cell, the four loop variants that made it static
+//
+// item_fused2_kernel: the operator fragments of a WHOLE CELL are prefetched one cell ahead
+// (fc / fn, static register indices).  Its predecessor streamed them through a 4-deep ring
+// whose slot phase moved from cell to cell; the four loop variants that made the phase static
 // were joined by the compiler with s_waitcnt vmcnt(0) and some forty register moves at every
 // cell boundary (a quarter of a five-step cell).  Cells have at most FZ_CELL_STEPS k-steps
 // (the host splits longer ones; pieces share the cell's scale / shift through cells.stat).

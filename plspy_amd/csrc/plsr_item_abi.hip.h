@@ -7,7 +7,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 
 using namespace plsr;
 
@@ -125,7 +124,6 @@ namespace {
 struct FusedPlan {
   FusedCells cells;    // the cells of the statistics (caller's cells)
   FusedCells kcells;   // the cells item_fused2_kernel walks: pieces of at most FZ_CELL_STEPS k-steps
-  bool v2;
   int MC, NT, TVX, VB, waves, nsplit, nchunk, flat, nslabm;
   int64_t nvt, nslab;
   size_t lds;
@@ -167,17 +165,13 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
   pl.cells.step_lo[ncell] = steps;
   pl.cells.nkp = steps;
   // kernel cells: every cell cut into pieces of FZ_CELL_STEPS k-steps (the cuts fall on whole
-  // k-steps, so the padded step count does not change); PLSR_K4F_RING=1 keeps the ring kernel
-  pl.v2 = getenv("PLSR_K4F_RING") == nullptr;
+  // k-steps, so the padded step count does not change)
   pl.kcells = pl.cells;
-  if (pl.v2) {
+  {
     int kc = 0, ks = 0;
-    for (int c = 0; c < ncell && pl.v2; ++c) {
+    for (int c = 0; c < ncell; ++c) {
       for (int lo = cell_lo[c]; lo < cell_lo[c + 1]; lo += 4 * FZ_CELL_STEPS) {
-        if (kc >= FZ_MAXCELL) {
-          pl.v2 = false;
-          break;
-        }
+        if (kc >= FZ_MAXPIECE) return false;
         const int hi = std::min(cell_lo[c + 1], lo + 4 * FZ_CELL_STEPS);
         pl.kcells.row_lo[kc] = lo;
         pl.kcells.step_lo[kc] = ks;
@@ -187,14 +181,10 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
         ++kc;
       }
     }
-    if (pl.v2) {
-      pl.kcells.ncell = kc;
-      pl.kcells.row_lo[kc] = cell_lo[ncell];
-      pl.kcells.step_lo[kc] = ks;
-      pl.kcells.nkp = ks;
-      if (ks != steps) pl.v2 = false;
-    }
-    if (!pl.v2) pl.kcells = pl.cells;
+    pl.kcells.ncell = kc;
+    pl.kcells.row_lo[kc] = cell_lo[ncell];
+    pl.kcells.step_lo[kc] = ks;
+    pl.kcells.nkp = ks;
   }
   pl.nvt = (p + pl.TVX - 1) / pl.TVX;
   pl.nsplit = (int)std::min<int64_t>(items, std::max<int64_t>(1, (1024 + pl.nvt - 1) / pl.nvt));
@@ -233,7 +223,7 @@ bool fused_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const 
 
 template <int NT, int TVX>
 int run_fused(const FusedArgs &a, const FusedPlan &pl, hipStream_t st) {
-  auto kern = pl.v2 ? item_fused2_kernel<NT, TVX> : item_fused_kernel<NT, TVX>;
+  auto kern = item_fused2_kernel<NT, TVX>;
   if (pl.lds > 64 * 1024 &&
       hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
     return PLSR_ELAUNCH;

@@ -33,12 +33,7 @@ def _zscore_items(X, src, cell_lo, zflags):
     return Z
 
 
-@pytest.mark.parametrize("ring", [False, True])
-def test_fused_items_random_shapes(ring, monkeypatch):
-    """K4f against NumPy.  ring=True forces the ring kernel (item_fused_kernel), which otherwise
-    only serves as the fallback of item_fused2_kernel for more than 64 cell pieces."""
-    if ring:
-        monkeypatch.setenv("PLSR_K4F_RING", "1")
+def test_fused_items_random_shapes():
     import torch
     from plspy_amd.engine import ProjectionEngine
     rs = np.random.RandomState(11)
