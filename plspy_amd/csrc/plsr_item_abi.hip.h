@@ -13,10 +13,15 @@ using namespace plsr;
 namespace {
 int launch_ok() { return hipGetLastError() == hipSuccess ? PLSR_OK : PLSR_ELAUNCH; }
 
-// items per workgroup of the latent kernel: bounded by the accumulator tiles
-// (IG * MC * NI x 8 VGPRs) that fit without scratch
+// items per workgroup of the latent kernel.  Items of a group share every staged X tile, but
+// the accumulators (IG * MC * NI x 8 VGPRs) decide how many waves a SIMD holds: from three
+// tiles of latent variables on (k > 32) a single item per workgroup -- 114 VGPRs, two
+// workgroups per CU, four waves per SIMD -- beats three items at two waves per SIMD by 9 %
+// (config 3: 133 -> 121 ms per 2000 items) although X is then staged once per item; below,
+// where the X tile dominates the traffic, up to three items share it (more spilled).
 constexpr int latent_group_cap(int mc, int ni) {
-  const int c = 10 / (mc * ni);      // (12 let the 4 x 1 x 3, 2 x 2 x 3 and 3 x 2 x 2 instances spill 24-350 B per lane)
+  if (mc >= 3) return 1;
+  const int c = 10 / (mc * ni);
   return c < 1 ? 1 : (c > 3 ? 3 : c);
 }
 
