@@ -739,7 +739,9 @@ inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp, i
 // leave each SIMD with a single wave (LDS-fed fp64 MFMA: 58 TFLOP/s at one wave per SIMD,
 // 66 at two, microbench/mfma_f64_data) -- eight waves then, if the per-wave patches still fit.
 inline int lds_fed_waves(int nk, int period, bool boot, int nh, int kp) {
-  if ((size_t)nk * 4 * TV * sizeof(double) <= 72 * 1024) return WAVES;
+  // (the permutation instance needs 94 VGPRs only: from two workgroups per CU on -- X tile above
+  // 36 KB, n > 72 -- eight waves each put four waves on a SIMD: -2.5 % at n = 120)
+  if ((size_t)nk * 4 * TV * sizeof(double) <= (boot ? 72 : 36) * 1024) return WAVES;
   return project_lds_bytes(nk, period, boot, nh, kp, 2 * WAVES) <= 160 * 1024 ? 2 * WAVES : WAVES;
 }
 
