@@ -626,6 +626,7 @@ __global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) 
       double *tp = A.T_part + (vt * C + (int64_t)t * 16 + col) * A.k2;     // never dereferenced when k2 = 0
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
+        if (NHT >= 0 && h >= NHT) continue;      // (compile-time: the number of stores stays fixed)
         const int cell = 4 * h + g;
         double *dst = cell < A.k2 ? tp + cell : A.sink + lane;
         *dst = Tout[h];
