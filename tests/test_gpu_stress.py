@@ -113,10 +113,10 @@ def test_projection_phases_random_shapes():
     the dumped VS for random n, k (all periods incl. padded ones), R, p."""
     from plspy_amd.engine import ProjectionEngine
     rs = np.random.RandomState(13)
-    # the last eight trials have n > 144: the LDS-fed kernel then runs eight waves per
-    # workgroup (one workgroup per CU), up to the largest n whose tile still fits (256)
-    big_n = [145, 150, 197, 240, 240, 252, 256, 256]
-    for trial in range(28):
+    # the last trials have larger n: from n > 72 the LDS-fed permutation kernel, from n > 144 the
+    # bootstrap kernel too, run eight waves per workgroup, up to the largest n whose tile fits (256)
+    big_n = [73, 100, 120, 144, 145, 150, 197, 240, 240, 252, 256, 256]
+    for trial in range(32):
         n = int(rs.randint(3, 70)) if trial < 20 else big_n[trial - 20]
         p = int(rs.choice([1, 63, 64, 65, 257]))
         k = int(rs.randint(1, 15))
