@@ -79,15 +79,15 @@ __device__ __forceinline__ int xs_index(int row, int v) {
 // hot bootstrap instance (a run-time count in the unrolled MFMA loop costs ~15 %);
 // -1 = take it from the arguments (dump mode), 0 = no second matrix.
 template <int PERIOD, int MODE, int NHT>
-__global__ __launch_bounds__(512, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
+__global__ __launch_bounds__(MODE == 0 ? 1024 : 768, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
   constexpr bool BOOT = MODE != 0;
   constexpr bool DUMP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // four waves per workgroup, or eight when the X tile leaves room for one workgroup per CU
-  // only (n > 144): two waves per SIMD instead of one (lds_fed_waves)
+  // four waves per workgroup, or eight and more when the X tile leaves room for one or two
+  // workgroups per CU only (lds_fed_waves)
   const int NW = blockDim.x >> 6;
   const int col = lane & 15;
   const int g = lane >> 4;
@@ -740,9 +740,17 @@ inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp, i
 // leave each SIMD with a single wave (LDS-fed fp64 MFMA: 58 TFLOP/s at one wave per SIMD,
 // 66 at two, microbench/mfma_f64_data) -- eight waves then, if the per-wave patches still fit.
 inline int lds_fed_waves(int nk, int period, bool boot, int nh, int kp) {
+  const size_t tile = (size_t)nk * 4 * TV * sizeof(double);
   // (the permutation instance needs 94 VGPRs only: from two workgroups per CU on -- X tile above
   // 36 KB, n > 72 -- eight waves each put four waves on a SIMD: -2.5 % at n = 120)
-  if ((size_t)nk * 4 * TV * sizeof(double) <= (boot ? 72 : 36) * 1024) return WAVES;
+  if (tile <= (size_t)(boot ? 72 : 36) * 1024) return WAVES;
+  if (tile > 72 * 1024) {
+    // one workgroup per CU: as many waves as the registers (bootstrap 165 VGPRs: three per
+    // SIMD; permutation: four) and the per-wave patches in LDS allow -- config 5 (n = 240):
+    // ten / fourteen waves, another 2 % over eight
+    for (int nw = boot ? 12 : 16; nw > 2 * WAVES; nw -= 2)
+      if (project_lds_bytes(nk, period, boot, nh, kp, nw) <= 160 * 1024) return nw;
+  }
   return project_lds_bytes(nk, period, boot, nh, kp, 2 * WAVES) <= 160 * 1024 ? 2 * WAVES : WAVES;
 }
 
