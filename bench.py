@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: resamples/sec (perm + boot) for mct PLS, X = 60 x 200 000.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1
-launched under torch.distributed.run, one rank per GPU.  One *step* is one pass
-of the resampling hot path over BASELINE.json's config 2 per GPU: 1000
-permutation + 1000 bootstrap resamples of the HBM-resident 60 x 200 000 fp64
-matrix (weak scaling: every rank owns that many resamples of a job N times as
-large; the per-phase RCCL exchange of dist.py is inside the timed region).
-Index tables are generated before the timed region and resident in HBM, so
-``value`` is the kernel-side rate; the end-to-end rate with NumPy-legacy index
-generation on the host is reported beside it.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the ranks are
+either started by a launcher (``python -m torch.distributed.run ... bench.py --gpus N``: RANK /
+WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment) or -- when those variables are absent --
+by this script itself: the parent then starts ``torch.distributed.run`` as a child process
+BEFORE anything touches the GPU (it never imports torch), relays rank 0's JSON line and exits
+with the child's code.  One rank per GPU, RCCL (backend "nccl") over xGMI.
+
+One *step* is one pass of the resampling hot path over BASELINE.json's config 2: permutation +
+bootstrap resamples of the HBM-resident 60 x 200 000 fp64 matrix, the per-phase collectives of
+plspy_amd/dist.py inside the timed region.  Two jobs are timed back to back:
+
+  strong  the north_star's FIXED job, 1000 permutations + 1000 bootstraps in total, sharded
+          over the N GPUs (``"scaling": "strong"``, the default ``value``);
+  weak    1000 + 1000 per GPU (the job grows with N; ``--scaling weak`` makes it ``value``).
+
+At N = 1 the two are the same job and it is timed once.  Index tables are generated before the
+timed region and resident in HBM, so ``value`` is the kernel-side rate; the end-to-end rate
+with the (native, NumPy-legacy bit-exact) index generation on the host is reported beside it.
 
 The JSON line also carries
-  roofline      -- dominant kernel (bootstrap projection) against the fp64 MFMA
-                   peak, duration from hipEvents on the launch stream
-  cpu_baseline  -- the NumPy oracle (reference-style direct path) timed on this
-                   box's host cores on a bounded sample of the same workload.
+  roofline      -- dominant kernel (bootstrap projection) against the fp64 MFMA peak, duration
+                   from hipEvents recorded on the launch stream inside the library
+  cpu_baseline  -- the NumPy oracle (reference-style direct path) timed on this box's host
+                   cores on a bounded sample of the same workload (N = 1, rank 0 only)
+  pls_call      -- the public seam: ``plspy_amd.PLS(X, ...)`` end to end, X upload, observed
+                   decomposition, index draws and host summaries included (N = 1 only).
 """
 import argparse
 import ctypes
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,41 +52,125 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix peak (AMD data sheet; the
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps per job (250 x 4.7 ms > 1 s at N = 1)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="which job's rate is `value` (both are timed and reported when N > 1)")
     ap.add_argument("--cpu-iters", type=int, default=120, help="oracle iterations per loop for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pls-call", action="store_true", help="skip the PLS()-level rates")
     ap.add_argument("--verify", action="store_true",
-                    help="after the timed steps, rank 0 recomputes the whole job alone and compares it with "
+                    help="after the timed steps, rank 0 recomputes each whole job alone and compares it with "
                          "what the ranks exchanged (test switch; outside the timed region)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------
+# self-launch (N > 1 without a launcher)
+# ---------------------------------------------------------------------------
+def self_launch(args):
+    """Start N fresh rank processes through torch.distributed.run and relay their output.
+    Runs before any GPU call: this process has not imported torch and never will."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, cwd=ROOT, env=env)           # stdout / stderr inherited: rank 0's JSON line passes through
+    return proc.returncode
+
+
+# ---------------------------------------------------------------------------
+# host cores actually available to the CPU baseline
+# ---------------------------------------------------------------------------
+def usable_cpus():
+    """CPUs this process may use: scheduler affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n, quota
+
+
 def cpu_baseline(X, co, obs, iters):
-    """Reference-style NumPy path (oracle) on the host cores: `iters`
-    permutations + `iters` bootstraps of the same 60 x 200 000 problem."""
+    """Reference-style NumPy path (oracle) on the host cores: `iters` permutations + `iters`
+    bootstraps of the same 60 x 200 000 problem, BLAS threads = the CPUs the cgroup grants."""
     from oracle import plspy_oracle as orc
+    ncpu, quota = usable_cpus()
     U, s, V = obs["U"], obs["s"], obs["V"]
-    np.random.seed(1234)
-    t0 = time.perf_counter()
-    perm = orc.permutation_test("mct", X, None, U, s, V, co, 0, iters)
-    orc.bootstrap_test("mct", X, None, U, perm["s"], V, co, 0, iters, Tvsc_orig=obs["Tvsc_orig"])
-    dt = time.perf_counter() - t0
+
+    def run():
+        np.random.seed(1234)
+        t0 = time.perf_counter()
+        perm = orc.permutation_test("mct", X, None, U, s, V, co, 0, iters)
+        orc.bootstrap_test("mct", X, None, U, perm["s"], V, co, 0, iters, Tvsc_orig=obs["Tvsc_orig"])
+        return time.perf_counter() - t0
+    blas = None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        with threadpool_limits(limits=ncpu):
+            blas = sorted({(d.get("internal_api"), d.get("num_threads")) for d in threadpool_info()})
+            dt = run()
+    except ImportError:
+        dt = run()
     return {
-        "value": 2 * iters / dt, "unit": "resamples/s", "cores": os.cpu_count(), "kind": "port",
-        "sample": f"{iters} perm + {iters} boot iterations of the same 60x200000 mct problem "
-                  f"(NumPy oracle, BLAS threads = all cores), {dt:.1f} s",
+        "value": 2 * iters / dt, "unit": "resamples/s", "cores": ncpu, "kind": "port",
+        "sample": f"{iters} perm + {iters} boot iterations of the same 60x200000 mct problem (NumPy oracle, "
+                  f"direct form), {dt:.1f} s; threads limited to the {ncpu} CPUs usable here "
+                  f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota {quota}, os.cpu_count {os.cpu_count()}); "
+                  f"BLAS pools {blas}",
     }
 
 
+def pls_call_rates(X):
+    """The public seam, end to end: plspy_amd.PLS(X, groups, 3, num_perm, num_boot) with X a host
+    array (upload, observed decomposition on the device, index draws, both tests, host summaries)."""
+    import plspy_amd
+    out = {}
+    for name, Xh, groups, R, reps in (("config2", X, [10, 10], 1000, 4), ("config5", None, [20] * 4, 5000, 2)):
+        if Xh is None:
+            Xh = np.random.RandomState(0).randn(240, 500_000)
+        times = []
+        for _ in range(reps):
+            np.random.seed(1234)
+            t0 = time.perf_counter()
+            plspy_amd.PLS(Xh, groups, 3, num_perm=R, num_boot=R, pls_method="mct")
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        out[name] = {"resamples_per_s": 2 * R / best, "seconds_warm": best, "seconds_first_call": times[0],
+                     "workload": f"PLS(X {Xh.shape[0]}x{Xh.shape[1]} host array, {groups} x 3, num_perm={R}, num_boot={R})"}
+    return out
+
+
+# ---------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     import torch.distributed as td
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
         # one rank per GPU over RCCL.  PLSR_DIST_BACKEND=gloo is a rehearsal
         # switch for boxes with fewer GPUs than ranks (ranks then share devices).
@@ -85,7 +183,8 @@ def main():
             td.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from plspy_amd import _lib, dist, operators, resample
     from plspy_amd.engine import ProjectionEngine
@@ -103,97 +202,119 @@ def main():
     M = W.T @ U
     ref = eng.dev(V * s)
     Xm = eng.apply_operator(Wm)
-
-    # weak scaling: the job is `world` times config 2; every rank owns 1000+1000
-    RP, RB = NPERM * world, NBOOT * world
-    np.random.seed(1234)
-    t0 = time.perf_counter()
-    perm_inds = resample.task_permutations(co, RP) if rank == 0 else None
-    boot_inds = resample.bootstraps(co, RB) if rank == 0 else None
-    t_index = time.perf_counter() - t0
-    perm_inds = dist.broadcast_indices(perm_inds, eng.device)
-    boot_inds = dist.broadcast_indices(boot_inds, eng.device)
-    plo, phi = dist.shard_bounds(RP, rank, world)
-    blo, bhi = dist.shard_bounds(RB, rank, world)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    d_perm = eng.dev(perm_inds[plo:phi], torch.int32)      # resident before the timed region
-    d_boot = eng.dev(boot_inds[blo:bhi], torch.int32)
-    torch.cuda.synchronize()
-    t_index += time.perf_counter() - t0                    # end-to-end rate: generation + upload of the tables
     Md = eng.dev(M)
-
-    def step():
-        # the two phases are independent: the HBM-bound slab reductions that end the
-        # bootstrap phase run on the engine's tail stream and overlap the MFMA-bound
-        # permutation kernel (the projection kernels themselves stay serialised)
-        res = eng.boot_phase(k, inds=d_boot, M=Md, ref=ref, Xm=Xm, overlap_tail=True)
-        ssq = eng.perm_phase(k, inds=d_perm, M=Md)
-        if world > 1:
-            # the bootstrap's collectives are enqueued behind its reduction tail, on the
-            # tail stream: the moment sums cross xGMI while the permutation kernel runs
-            with eng.tail_stream():
-                (bs, T), (S1, S2) = dist.exchange([res["ssq"], res["T"]], [res["S1"], res["S2"]], RB)
-            eng.join()
-            for t in (bs, T, S1, S2):
-                t.record_stream(torch.cuda.current_stream())
-            (ssq_all,), _ = dist.exchange([ssq], [], RP)
-        else:
-            eng.join()
-            ssq_all, bs, T, S1, S2 = ssq, res["ssq"], res["T"], res["S1"], res["S2"]
-        sd, ratio = eng.boot_finalize(S1, S2, RB, num=ref)
-        return ssq_all, bs, T, sd, ratio
 
     def fence():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
-    # setup, before the W warm-up steps: first-use allocations of the scratch and the
-    # device's clock ramp -- from idle the same kernels take 3.1 ms instead of 2.7 ms for the
-    # first ~25 ms of load (measured: --warmup 0 / 1 / 2 / 3 / 5 -> 16.4 / 5.57 / 5.33 / 5.21 /
-    # 4.95 ms for the step that follows), so a short W would time the ramp, not the path
-    for _ in range(8):
-        step()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    lib.plsr_timing_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.plsr_timing_enable(0)
-    ms = (ctypes.c_double * 4096)()
-    kind = (ctypes.c_int32 * 4096)()
-    nt = lib.plsr_timing_collect(ms, kind, 4096)
-    boot_ms = [ms[i] for i in range(nt) if kind[i] == 1]
-    perm_ms = [ms[i] for i in range(nt) if kind[i] == 0]
+    def make_job(RP, RB):
+        """Index tables of a job of RP + RB resamples: drawn on rank 0 in the reference's RNG
+        order, broadcast, this rank's contiguous block uploaded."""
+        np.random.seed(1234)
+        t0 = time.perf_counter()
+        perm_inds = resample.task_permutations(co, RP) if rank == 0 else None
+        boot_inds = resample.bootstraps(co, RB) if rank == 0 else None
+        t_index = time.perf_counter() - t0
+        perm_inds = dist.broadcast_indices(perm_inds, eng.device)
+        boot_inds = dist.broadcast_indices(boot_inds, eng.device)
+        plo, phi = dist.shard_bounds(RP, rank, world)
+        blo, bhi = dist.shard_bounds(RB, rank, world)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_perm = eng.dev(perm_inds[plo:phi], torch.int32)      # resident before the timed region
+        d_boot = eng.dev(boot_inds[blo:bhi], torch.int32)
+        torch.cuda.synchronize()
+        t_index += time.perf_counter() - t0                    # end-to-end rate: generation + upload of the tables
+        return dict(RP=RP, RB=RB, perm_inds=perm_inds, boot_inds=boot_inds, d_perm=d_perm, d_boot=d_boot,
+                    t_index=t_index, local_boot=bhi - blo, local_perm=phi - plo)
 
-    if args.verify and rank == 0:
+    def make_step(job):
+        RP, RB, d_perm, d_boot = job["RP"], job["RB"], job["d_perm"], job["d_boot"]
+
+        def step():
+            # the two phases are independent: the HBM-bound slab reductions that end the
+            # bootstrap phase run on the engine's tail stream and overlap the MFMA-bound
+            # permutation kernel (the projection kernels themselves stay serialised)
+            res = eng.boot_phase(k, inds=d_boot, M=Md, ref=ref, Xm=Xm, overlap_tail=True)
+            ssq = eng.perm_phase(k, inds=d_perm, M=Md)
+            if world > 1:
+                # the bootstrap's collectives (one all_gather of the per-resample rows, one
+                # all_reduce of the moment block) are enqueued behind its reduction tail, on the
+                # tail stream: the moment sums cross xGMI while the permutation kernel runs
+                with eng.tail_stream():
+                    (bs, T), (S12,) = dist.exchange([res["ssq"], res["T"]], [res["S12"]], RB)
+                eng.join()
+                for t in (bs, T, S12):
+                    t.record_stream(torch.cuda.current_stream())
+                (ssq_all,), _ = dist.exchange([ssq], [], RP)
+            else:
+                eng.join()
+                ssq_all, bs, T, S12 = ssq, res["ssq"], res["T"], res["S12"]
+            sd, ratio = eng.boot_finalize(S12[0], S12[1], RB, num=ref)
+            return ssq_all, bs, T, sd, ratio
+        return step
+
+    def time_job(job, steps, warmup):
+        step = make_step(job)
+        for _ in range(warmup):
+            step()
+        fence()
+        lib.plsr_timing_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        lib.plsr_timing_enable(0)
+        cap = 2 * steps + 64
+        ms = (ctypes.c_double * cap)()
+        kind = (ctypes.c_int32 * cap)()
+        nt = lib.plsr_timing_collect(ms, kind, cap)
+        boot_ms = [ms[i] for i in range(nt) if kind[i] == 1]
+        perm_ms = [ms[i] for i in range(nt) if kind[i] == 0]
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device=eng.device if (world == 1 or td.get_backend() == "nccl") else "cpu")
+        if world > 1:
+            td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        return float(tmax.item()), boot_ms, perm_ms, out
+
+    def verify(job, out, label):
         # the whole job (all ranks' resamples) on this rank alone, without any exchange
-        full_b = eng.boot_phase(k, inds=eng.dev(boot_inds, torch.int32), M=Md, ref=ref, Xm=Xm)
-        full_p = eng.perm_phase(k, inds=eng.dev(perm_inds, torch.int32), M=Md)
-        sd1, ratio1 = eng.boot_finalize(full_b["S1"], full_b["S2"], RB, num=ref)
+        full_b = eng.boot_phase(k, inds=eng.dev(job["boot_inds"], torch.int32), M=Md, ref=ref, Xm=Xm)
+        full_p = eng.perm_phase(k, inds=eng.dev(job["perm_inds"], torch.int32), M=Md)
+        sd1, ratio1 = eng.boot_finalize(full_b["S1"], full_b["S2"], job["RB"], num=ref)
         torch.cuda.synchronize()
         for name, got, want in (("perm ssq", out[0], full_p), ("boot ssq", out[1], full_b["ssq"]),
                                 ("T", out[2], full_b["T"]), ("std_errs", out[3], sd1), ("boot_ratios", out[4], ratio1)):
             g, w = got.cpu().numpy(), want.cpu().numpy()
             assert g.shape == w.shape, (name, g.shape, w.shape)
             err = float(np.max(np.abs(g - w)) / max(np.max(np.abs(w)), 1e-300))
-            assert err < 1e-11, f"--verify: {name} differs from the single-rank result by {err:.2e} (relative)"
-        print(f"[verify] {world} rank(s): exchanged results match the single-rank recomputation", file=sys.stderr)
+            assert err < 1e-11, f"--verify ({label}): {name} differs from the single-rank result by {err:.2e} (relative)"
+        print(f"[verify] {world} rank(s), {label} job: exchanged results match the single-rank recomputation",
+              file=sys.stderr)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64,
-                        device=eng.device if (world == 1 or td.get_backend() == "nccl") else "cpu")
+    # setup, before the W warm-up steps: first-use allocations of the scratch and the
+    # device's clock ramp -- from idle the same kernels take 3.1 ms instead of 2.7 ms for the
+    # first ~25 ms of load (measured: --warmup 0 / 1 / 2 / 3 / 5 -> 16.4 / 5.57 / 5.33 / 5.21 /
+    # 4.95 ms for the step that follows), so a short W would time the ramp, not the path
+    jobs = {"strong": make_job(NPERM, NBOOT)}
     if world > 1:
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        jobs["weak"] = make_job(NPERM * world, NBOOT * world)
+    spin = make_step(jobs["strong"])
+    for _ in range(8):
+        spin()
+    results = {}
+    for label, job in jobs.items():
+        elapsed, boot_ms, perm_ms, out = time_job(job, args.steps, args.warmup)
+        results[label] = dict(elapsed=elapsed, boot_ms=boot_ms, perm_ms=perm_ms)
+        if args.verify and rank == 0:
+            verify(job, out, label)
+    if world == 1:
+        jobs["weak"], results["weak"] = jobs["strong"], results["strong"]
 
     if rank == 0:
-        total = (RP + RB) * args.steps
-        value = total / elapsed
         n, p = N_ROWS, P_VOX
         # algorithmic flops per resample, dense direct form (SURVEY.md 8(d)):
         #   perm  2knp + 2k^2p ; boot kernel = VS (2knp + 2k^2p) + Tdistrib (2nkp)
@@ -206,9 +327,25 @@ def main():
         # of four cells (v_mfma_f64_4x4x4_4b: 8 flop per half per column-voxel)
         x_perm = 2 * n * k * p
         x_boot = x_perm + 8 * ((k + 3) // 4) * k * p
-        per_launch = NBOOT
-        bm = float(np.mean(boot_ms)) if boot_ms else float("nan")
-        pm = float(np.mean(perm_ms)) if perm_ms else float("nan")
+
+        def summary(label):
+            job, r = jobs[label], results[label]
+            total = (job["RP"] + job["RB"]) * args.steps
+            return {
+                "value": total / r["elapsed"], "unit": "resamples/s", "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                "job": f"{job['RP']} perm + {job['RB']} boot in total, {job['local_perm']} + {job['local_boot']} on rank 0",
+                "end_to_end_resamples_per_s": total / (r["elapsed"] + job["t_index"] * args.steps),
+                "host_index_generation_and_upload_s_per_step": job["t_index"],
+                "boot_launch_ms": float(np.mean(r["boot_ms"])) if r["boot_ms"] else None,
+                "perm_launch_ms": float(np.mean(r["perm_ms"])) if r["perm_ms"] else None,
+            }
+        main_label = args.scaling
+        sm = {lab: summary(lab) for lab in ("strong", "weak")}
+        head = sm[main_label]
+        job, r = jobs[main_label], results[main_label]
+        per_launch = job["local_boot"]                  # resamples one launch of the dominant kernel processes
+        bm = float(np.mean(r["boot_ms"])) if r["boot_ms"] else float("nan")
+        pm = float(np.mean(r["perm_ms"])) if r["perm_ms"] else float("nan")
         # `achieved` is priced on the flops the MFMA pipe executes (<= peak by
         # construction).  The reference-form ("algorithmic") rate is reported
         # beside it: the kernel gets the same numbers with fewer flops, so that
@@ -216,25 +353,29 @@ def main():
         achieved = x_boot * per_launch / (bm * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and per_launch == NBOOT:
             traffic = json.load(open(tpath)).get("boot_project_bytes_per_launch")
         line = {
             "metric": "resamples/sec (perm+boot), mct PLS X=60x200000",
-            "value": value, "unit": "resamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": head["value"], "unit": "resamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": main_label, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: mct PLS, X=(60x200000) fp64, groups=[10,10] x 3 "
-                                   "conditions, 1000 perm + 1000 boot per GPU per step",
+            "config": {"workload": "BASELINE config 2: mct PLS, X=(60x200000) fp64, groups=[10,10] x 3 conditions, "
+                                   + ("1000 perm + 1000 boot per step in total (fixed job, sharded over the GPUs)"
+                                      if main_label == "strong" else "1000 perm + 1000 boot per GPU per step"),
                        "indices": "resident in HBM before the timed region",
                        "parallelism": f"resample-sharded x{world}"},
-            "end_to_end_resamples_per_s": total / (elapsed + t_index * args.steps / 1.0),
-            "host_index_generation_and_upload_s_per_step": t_index,
+            "backend": (td.get_backend() if world > 1 else None),
+            "world_size": (td.get_world_size() if world > 1 else 1),
+            "strong": sm["strong"], "weak": sm["weak"],
+            "end_to_end_resamples_per_s": head["end_to_end_resamples_per_s"],
+            "host_index_generation_and_upload_s_per_step": head["host_index_generation_and_upload_s_per_step"],
             "roofline": {
                 "bound": "mfma", "kernel": "plsr::project_boot_reg_kernel<15, false, 2> (bootstrap projection, K1br)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "avg_launch_ms": bm, "launches": len(boot_ms),
+                "avg_launch_ms": bm, "launches": len(r["boot_ms"]), "resamples_per_launch": per_launch,
                 "algorithmic_flop_per_resample": f_boot,
                 "executed_flop_per_resample": x_boot,
                 "algorithmic_equivalent_tflops": f_boot * per_launch / (bm * 1e-3) / 1e12,
@@ -245,18 +386,20 @@ def main():
                 "unbatched_bytes_per_resample": 8 * n * p,
                 "unbatched_hbm_equivalent_TBps": 8 * n * p * per_launch / (bm * 1e-3) / 1e12,
                 "unbatched_hbm_equivalent_frac_of_8TBps": 8 * n * p * per_launch / (bm * 1e-3) / 8e12,
-                "perm_kernel": {"avg_launch_ms": pm, "launches": len(perm_ms),
-                                "achieved": x_perm * NPERM / (pm * 1e-3) / 1e12,
-                                "algorithmic_equivalent_tflops": f_perm * NPERM / (pm * 1e-3) / 1e12},
+                "perm_kernel": {"avg_launch_ms": pm, "launches": len(r["perm_ms"]),
+                                "achieved": x_perm * job["local_perm"] / (pm * 1e-3) / 1e12,
+                                "algorithmic_equivalent_tflops": f_perm * job["local_perm"] / (pm * 1e-3) / 1e12},
             },
         }
         if not args.no_cpu and world == 1:          # the CPU baseline is an N = 1 figure (rank 0's host cores)
-            from oracle import plspy_oracle as orc
             obs = {"U": U, "s": s, "V": V, "Tvsc_orig": Wm @ (X @ V)}
             line["cpu_baseline"] = cpu_baseline(X, co, obs, args.cpu_iters)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        if not args.no_pls_call and world == 1:
+            line["pls_call"] = pls_call_rates(X)
+            line["pls_call_resamples_per_s"] = line["pls_call"]["config2"]["resamples_per_s"]
+        print(json.dumps(line), flush=True)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -97,6 +97,17 @@ int plsr_ops_from_behaviour(const double *d_Yz, int32_t nb, const double *d_U,
 size_t plsr_batch_workspace_bytes(const plsr_layout_t *lay, int64_t p, int32_t k2);
 
 /*
+ * Launch shape the two batch calls below choose for (lay, p, k2) -- a query for tests and
+ * profiles, no device work.  out[0] = voxel tiles (grid.x); out[1] = batch-column splits
+ * (LV-major layout: runs per latent variable, grid.y = k * out[1]); out[2] = batch tiles per
+ * latent variable (LV-major) or total batch tiles (quad layout); out[3] = 1 if the
+ * register-resident kernels (n <= 64) serve, else 0.  `boot` selects the bootstrap launch.
+ * (No reference counterpart: the reference runs one resample per loop iteration,
+ * bootstrap_permutation.py:323, :537.)
+ */
+int plsr_batch_plan(const plsr_layout_t *lay, int64_t p, int32_t k2, int32_t boot, int32_t out[4]);
+
+/*
  * Permutation batch.  For every resample b and latent variable j:
  *     d_ssq[b][j] = sum_v ( sum_i X[i,v] * op_(b,j)[i] )^2
  * i.e. s_hat^2 of bootstrap_permutation.py:404-405.

@@ -639,9 +639,14 @@ def _half_block(pls_alg, X1, Y1, co1, mctype, bscan, Xb1, Yb1):
 
 def split_half_both(pls_alg, matrix, Y, cond_order, num_split, mctype=None,
                     bscan=None, Ybscan=None, lv=1, CI=0.95, which="tt",
-                    sampler=None, contrasts=None):
+                    sampler=None, contrasts=None, only=None):
     """``which="tt"`` -> split_half_test_train (:23-401);
-    ``which="sh"`` -> split_half (:404-861).  Same splitting code in both."""
+    ``which="sh"`` -> split_half (:404-861).  Same splitting code in both.
+
+    ``only``: optional set of split numbers.  Every split is still drawn (the RNG stream is
+    the reference's), but only the listed real and null splits are decomposed -- the other
+    slabs stay zero and the summary statistics are then meaningless.  For full-size checks,
+    where one split costs seconds of LAPACK time."""
     sampler = sampler or Sampler()
     cond_order = np.asarray(cond_order)
     n, p = matrix.shape
@@ -661,6 +666,8 @@ def split_half_both(pls_alg, matrix, Y, cond_order, num_split, mctype=None,
     g1 = g2 = None
 
     def decompose(i, X1, X2, Y1, Y2, Xb1, Yb1, Xb2, Yb2, co1, co2, outA, outB):
+        if only is not None and i not in only:
+            return
         M1 = _half_block(pls_alg, X1, Y1, co1, mctype, bscan, Xb1, Yb1)
         M2 = _half_block(pls_alg, X2, Y2, co2, mctype, bscan, Xb2, Yb2)
         U1, s1, V1 = decomp(M1)

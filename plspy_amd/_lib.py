@@ -32,6 +32,7 @@ SIGNATURES = {
     "plsr_ops_pack": (c_i32, [c_vp, ctypes.POINTER(Layout), c_vp, c_vp]),
     "plsr_ops_from_behaviour": (c_i32, [c_vp, c_i32, c_vp, c_vp, ctypes.POINTER(Layout), c_vp, c_vp]),
     "plsr_batch_workspace_bytes": (c_sz, [ctypes.POINTER(Layout), c_i64, c_i32]),
+    "plsr_batch_plan": (c_i32, [ctypes.POINTER(Layout), c_i64, c_i32, c_i32, ctypes.POINTER(c_i32 * 4)]),
     "plsr_perm_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,
                                 c_sz, c_vp]),
     "plsr_boot_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,

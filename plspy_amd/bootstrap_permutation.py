@@ -19,11 +19,13 @@ boot_ratios, boot_debug_dict, ...).  What differs is how the numbers are made:
 
 Random draws replicate the reference's np.random call order (resample.py).
 
-Coverage: permutation and bootstrap tests for mct, rb and mb.  In the rb / mb
-bootstrap every resample z-scores its own resampled rows, so each resample
-gets its own gathered matrix (K3) and runs through the item kernels (K4 / K5).
-Contrast variants (cst / csb / cmb) raise NotImplementedError; nothing falls
-back to a CPU path."""
+Coverage: permutation and bootstrap tests for mct, rb, mb and the contrast
+variants cst / csb / cmb (projection on the normalised contrast matrix instead of
+the observed U, :429-433, :658-675).  In the rb / mb bootstrap every resample
+z-scores its own resampled rows, so each resample is an item of the fused item
+kernels (K4f / K5).  The csb bootstrap ends in the reference's own ValueError
+(pls_classes.py:1158 hands a q x q matrix to :725).  Nothing falls back to a CPU
+path."""
 import abc
 
 import numpy as np
@@ -372,8 +374,8 @@ class _ResampleTestPLS(ResampleTest):
         eng = self._engine
         eng.join()
         per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
-        per, (S1, S2) = dist.exchange(per, [res["S1"], res["S2"]], niter)
-        sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)          # :695, :701
+        per, (S12,) = dist.exchange(per, [res["S12"]], niter)
+        sd, ratio = eng.boot_finalize(S12[0], S12[1], niter, num=ref)  # :695, :701
         std_errs = sd.cpu().numpy()
         boot_ratios = ratio.cpu().numpy()
 
@@ -434,8 +436,9 @@ class _ResampleTestPLS(ResampleTest):
         eng = self._engine
         _, nranks = dist.world()
         if nranks > 1:
-            full, (S1, S2) = dist.exchange([eng.dev(a) for a in per_resample], [res["S1"], res["S2"]], niter)
+            full, (S12,) = dist.exchange([eng.dev(a) for a in per_resample], [res["S12"]], niter)
             per_resample = [t.cpu().numpy() for t in full]
+            S1, S2 = S12[0], S12[1]
         else:
             S1, S2 = res["S1"], res["S2"]
         sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)                  # :695, :701

@@ -364,9 +364,13 @@ int launch_boot_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
 // K1r: one wave per workgroup; the batch is split so that the grid has about
 // twenty rounds of the 2048 resident waves (a wave's X fragments cost 4 nk loads
 // per run, so runs should stay tens of tiles long)
+int perm_reg_split(int ntiles, int64_t nvt) {
+  const int nsplit = (int)std::min<int64_t>(ntiles, std::max<int64_t>(1, (20 * 2048 + nvt - 1) / nvt));
+  return std::min(nsplit, std::max(1, ntiles / 8));
+}
+
 int launch_perm_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
-  int nsplit = (int)std::min<int64_t>(a.ntiles, std::max<int64_t>(1, (20 * 2048 + nvt - 1) / nvt));
-  nsplit = std::min(nsplit, std::max(1, a.ntiles / 8));
+  const int nsplit = perm_reg_split(a.ntiles, nvt);
   ProjectKernel kern = nullptr;
   switch (a.nk) {
     case 4: kern = project_perm_reg_kernel<4>; break;
@@ -403,6 +407,21 @@ int launch_perm_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
 extern "C" size_t plsr_batch_workspace_bytes(const plsr_layout_t *lay, int64_t p, int32_t k2) {
   if (!lay || p <= 0 || k2 < 0) return 0;
   return carve(lay, p, k2, nullptr, true).bytes;
+}
+
+extern "C" int plsr_batch_plan(const plsr_layout_t *lay, int64_t p, int32_t k2, int32_t boot, int32_t out[4]) {
+  if (!lay || !out || p <= 0 || k2 < 0) return PLSR_EINVAL;
+  const Work w = carve(lay, p, k2, nullptr, boot != 0);
+  const bool reg = lay->period == 0;
+  out[0] = (int32_t)w.nvt;
+  if (reg && !boot) {
+    out[1] = perm_reg_split(lay->ntiles, w.nvt);          // K1r
+  } else {
+    out[1] = w.nsplit;
+  }
+  out[2] = reg ? lay_tpl(lay) : lay->ntiles;
+  out[3] = reg ? 1 : 0;
+  return PLSR_OK;
 }
 
 static int fill_common(ProjectArgs &a, const double *d_X, int64_t ldx, int64_t p,

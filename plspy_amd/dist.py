@@ -1,9 +1,9 @@
 """Sharding of resample ids over the GPUs of one node (one process per GPU).
 
 Resamples are independent, so the only exchange is one collective per phase
-(RCCL over xGMI; gloo in the CPU tests): an all_gather of the per-resample
-results (s_hat^2, Tdistrib numerators; rows concatenated in rank order) and,
-for the bootstrap, an all_reduce of the shifted moment sums.  Every rank ends
+(RCCL over xGMI; gloo in the CPU tests): one all_gather of the per-resample
+results (s_hat^2, Tdistrib numerators, packed; rows concatenated in rank order)
+and, for the bootstrap, one all_reduce of the shifted moment sums.  Every rank ends
 with bit-identical results.
 
 Index vectors are drawn once, on rank 0, in the reference's RNG order and
@@ -42,15 +42,18 @@ def broadcast_indices(inds, device=None):
 
 
 def exchange(per_resample, summed, R):
-    """The collectives of one phase: an all_gather of the ranks' per-resample
-    rows (small) and an all_reduce of the moment sums (2 p k doubles; an
-    all_gather of those would move world_size times the data over xGMI).
+    """The collectives of one phase: ONE all_gather of the ranks' per-resample rows (all
+    tensors packed into one buffer; small) and ONE all_reduce of the moment sums (2 p k
+    doubles; an all_gather of those would move world_size times the data over xGMI).
 
     per_resample: list of tensors whose dim 0 is this rank's resample block.
-    summed:       list of tensors to be added over ranks (moment sums).
-    Returns (list of full per-resample tensors, list of summed tensors); every
-    rank ends with bit-identical results (RCCL / gloo reduce each element along
-    one path and broadcast it)."""
+    summed:       list of tensors to be added over ranks (moment sums).  A single contiguous
+                  tensor that already lives where the backend reduces (the engine hands S1 / S2
+                  over as one (2, p, k) block) is reduced IN PLACE -- no staging copy.
+    Returns (list of full per-resample tensors, list of summed tensors); every rank ends with
+    bit-identical results (RCCL / gloo reduce each element along one path and broadcast it).
+    The sums depend on the number of ranks at rounding level (each rank adds its own block
+    first); the per-resample rows do not."""
     rank, n = world()
     if n == 1:
         return per_resample, summed
@@ -62,26 +65,35 @@ def exchange(per_resample, summed, R):
     if per_resample:
         bounds = [shard_bounds(R, r, n) for r in range(n)]
         maxrows = max(hi - lo for lo, hi in bounds)
+        even = all(hi - lo == maxrows for lo, hi in bounds)
         row_elems = [int(np.prod(t.shape[1:])) for t in per_resample]
-        send = torch.zeros(maxrows * sum(row_elems), dtype=torch.float64, device=dev)
+        send = (torch.empty if even else torch.zeros)(maxrows * sum(row_elems), dtype=torch.float64, device=dev)
         off = 0
         for t, re in zip(per_resample, row_elems):
-            send[off:off + t.numel()] = t.reshape(-1).to(dev)
+            send[off:off + t.numel()].copy_(t.reshape(-1))
             off += maxrows * re
-        recv = [torch.empty_like(send) for _ in range(n)]
-        td.all_gather(recv, send)
+        recv = torch.empty(n * send.numel(), dtype=torch.float64, device=dev)
+        td.all_gather_into_tensor(recv, send)
+        recv = recv.view(n, -1)
         off = 0
         for t, re in zip(per_resample, row_elems):
-            parts = [recv[r][off:off + (hi - lo) * re].reshape((hi - lo,) + tuple(t.shape[1:]))
-                     for r, (lo, hi) in enumerate(bounds)]
-            full.append(torch.cat(parts, dim=0).to(out_dev))
+            block = recv[:, off:off + maxrows * re].reshape((n, maxrows) + tuple(t.shape[1:]))
+            if even:
+                got = block.reshape((n * maxrows,) + tuple(t.shape[1:]))
+            else:
+                got = torch.cat([block[r, :hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
+            full.append(got.to(out_dev))
             off += maxrows * re
     sums = []
     if summed:
-        flat = torch.cat([t.reshape(-1).to(dev) for t in summed])
-        td.all_reduce(flat, op=td.ReduceOp.SUM)
-        off = 0
-        for t in summed:
-            sums.append(flat[off:off + t.numel()].reshape(t.shape).to(out_dev))
-            off += t.numel()
+        if len(summed) == 1 and summed[0].device == dev and summed[0].is_contiguous():
+            td.all_reduce(summed[0].view(-1), op=td.ReduceOp.SUM)
+            sums = [summed[0]]
+        else:
+            flat = torch.cat([t.reshape(-1).to(dev) for t in summed])
+            td.all_reduce(flat, op=td.ReduceOp.SUM)
+            off = 0
+            for t in summed:
+                sums.append(flat[off:off + t.numel()].reshape(t.shape).to(out_dev))
+                off += t.numel()
     return full, sums

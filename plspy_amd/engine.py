@@ -102,6 +102,15 @@ class ProjectionEngine:
                    f"plsr_layout_init(n={self.n}, k={k}, R={R})")
         return lay
 
+    def plan(self, k, R, k2=0, boot=True):
+        """Launch shape of a batch of R resamples (plsr_batch_plan): dict(voxel_tiles, splits,
+        tiles, register_resident)."""
+        lay = self.layout(k, R)
+        out = (ctypes.c_int32 * 4)()
+        _lib.check(self.lib.plsr_batch_plan(ctypes.byref(lay), self.p, k2, int(boot), ctypes.byref(out)),
+                   "plsr_batch_plan")
+        return dict(voxel_tiles=out[0], splits=out[1], tiles=out[2], register_resident=bool(out[3]))
+
     def batch_size(self, k, k2, R):
         """Largest batch (a multiple of 16 resamples, or all of them) whose
         scratch fits work_limit."""
@@ -200,8 +209,8 @@ class ProjectionEngine:
         refd = self.dev(ref)
         Xmd = self.dev(Xm)
         k2 = 0 if Xmd is None else int(Xmd.shape[0])
-        S1 = torch.zeros((self.p, k), dtype=torch.float64, device=self.device)
-        S2 = torch.zeros_like(S1)
+        S12 = torch.zeros((2, self.p, k), dtype=torch.float64, device=self.device)   # one block: one all_reduce
+        S1, S2 = S12[0], S12[1]
         ssq = torch.empty((R, k), dtype=torch.float64, device=self.device)
         T = torch.empty((R, k, k2), dtype=torch.float64, device=self.device) if k2 else None
         vs = torch.zeros((R, self.p, k), dtype=torch.float64, device=self.device) if dump else None
@@ -231,7 +240,7 @@ class ProjectionEngine:
                         "plsr_boot_batch")
             finally:
                 self.lib.plsr_set_tail_stream(ctypes.c_void_p(0))
-        return {"S1": S1, "S2": S2, "ssq": ssq, "T": T, "vs": vs, "R": R}
+        return {"S1": S1, "S2": S2, "S12": S12, "ssq": ssq, "T": T, "vs": vs, "R": R}
 
     def boot_finalize(self, S1, S2, R, num=None):
         """(std_errs, boot_ratios) from summed shifted moments."""
@@ -407,8 +416,8 @@ class ProjectionEngine:
         R, nz = src.shape
         n = self.n if latent_rows is None else int(latent_rows)
         refd = self.dev(ref)
-        S1 = torch.zeros((self.p, k), dtype=torch.float64, device=self.device)
-        S2 = torch.zeros_like(S1)
+        S12 = torch.zeros((2, self.p, k), dtype=torch.float64, device=self.device)
+        S1, S2 = S12[0], S12[1]
         Zt = torch.empty((R, k, n), dtype=torch.float64, device=self.device)
         nsq = torch.empty((R, k), dtype=torch.float64, device=self.device)
         ncell = len(cell_z)
@@ -467,7 +476,7 @@ class ProjectionEngine:
                 pending = (lo, hi, ev)
         if pending is not None:
             deliver(pending)
-        return {"S1": S1, "S2": S2, "Zt": Zt, "nsq": nsq, "R": R}
+        return {"S1": S1, "S2": S2, "S12": S12, "Zt": Zt, "nsq": nsq, "R": R}
 
     def eigh(self, G, off, k):
         """Eigen-decomposition of the k x k diagonal block at `off` of every

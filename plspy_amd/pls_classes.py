@@ -3,9 +3,10 @@
 Each class keeps the reference's constructor signature, validation, attribute
 names and the final U/V swap (plspy/core/pls_classes.py), so a result object
 can be consumed by code written against plspy (e.g. its visualize package).
-The observed decomposition is done once on the host exactly as the reference
-does it; the permutation / bootstrap / split-half loops run on the GPU through
-bootstrap_permutation.py and split_half_resampling.py."""
+The observed decomposition (class_functions.py:98-123) runs on the device
+(engine.thin_svd: Gram -> Jacobi -> back-projection), like the observed blocks and
+latent scores; the permutation / bootstrap / split-half loops run on the GPU
+through bootstrap_permutation.py and split_half_resampling.py."""
 import abc
 
 import numpy as np

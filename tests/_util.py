@@ -90,10 +90,22 @@ def nonnull(fx, tol=1e-10):
 
 
 def assert_close(a, b, rtol, atol=0.0, what=""):
+    """|a - b| <= atol + rtol * max(|a|, |b|) elementwise.  Non-finite entries must agree
+    exactly: NaN only where the other side has NaN, infinities equal in position and sign
+    (a NaN coming out of a kernel must never pass against a finite expected value)."""
     a, b = np.asarray(a, float), np.asarray(b, float)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), (f"{what}: NaN mismatch ({nan_a.sum()} in result, {nan_b.sum()} expected, "
+                                          f"{np.sum(nan_a != nan_b)} positions differ)")
+    inf_a, inf_b = np.isinf(a), np.isinf(b)
+    assert np.array_equal(inf_a, inf_b) and np.array_equal(a[inf_a], b[inf_b]), f"{what}: infinities differ"
+    fin = ~(nan_a | inf_a)
+    a, b = a[fin], b[fin]
+    if a.size == 0:
+        return
     err = np.abs(a - b)
     lim = atol + rtol * np.maximum(np.abs(a), np.abs(b))
-    bad = err > lim
+    bad = ~(err <= lim)
     assert not bad.any(), (f"{what}: {bad.sum()} of {bad.size} off; worst abs {err.max():.3e} "
                            f"rel {np.max(err / np.maximum(np.abs(b), 1e-300)):.3e}")

@@ -1,0 +1,284 @@
+"""GPU parity at BASELINE.json's FULL shapes (configs 2-5), i.e. the launch shapes and kernel
+instances the benchmarks time -- which the golden fixtures (p <= 1000, R <= 100) never reach.
+
+The oracle's direct form cannot run a whole phase at these sizes, so each
+statistic is compared through something that can:
+
+* voxel-LOCAL statistics (right_sv_sampled -> std_errs, boot_ratios, moment sums): the oracle /
+  direct NumPy on a voxel subset of X, over ALL resamples of the phase;
+* p-wide contractions of the linear (task) path (s_hat^2, Tdistrib numerators): the Gram
+  identity a^T (X X^T) a -- p-free, computed by NumPy, independent of the
+  kernels' tiling and reduction order;
+* p-wide nonlinear results (rb LVcorr, mb split-half slabs): the oracle's direct form at full
+  size for a handful of resamples / splits, chosen to straddle batch boundaries.
+
+Reference arithmetic: bootstrap_permutation.py:404-405, :617-634, :695; split_half_resampling.py
+:186-196, :612-683; class_functions.py:185-247, :454-516.  Tolerances are those of BASELINE.md
+(s_hat 1e-10 rel, bootstrap statistics 1e-9 / 1e-8 rel)."""
+import ctypes
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import plspy_oracle as orc
+from tests._util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _operators(M, inds):
+    """a[b] = P_b^T M (R, n, k): the direct statement of `W @ X[inds_b]` projected on U as an
+    operator on X -- VS_b = X^T a[b] with M = W^T U."""
+    R, n = inds.shape
+    a = np.zeros((R, n, M.shape[1]))
+    np.add.at(a, (np.arange(R)[:, None], inds), M[None])      # row i of X[inds] is X[inds[i]]
+    return a
+
+
+def _mct_problem(groups, nc, p, seed=0):
+    from plspy_amd import operators
+    co = np.array([[g] * nc for g in groups])
+    X = np.random.RandomState(seed).randn(int(co.sum()), p)
+    W = operators.mean_centre_operator(co, 0)
+    Wm = operators.cell_mean_operator(co)
+    U, s, Vt = np.linalg.svd(W @ X, full_matrices=False)
+    s[np.abs(s) < 1e-12] = 0
+    return co, X, W, Wm, U, s, Vt.T
+
+
+def _check_mct_phases(X, co, W, Wm, U, s, V, nperm, nboot, sub, overlap_tail=True):
+    """One bench.py step at the given shape, every output against NumPy."""
+    import torch
+    from plspy_amd import resample
+    from plspy_amd.engine import ProjectionEngine
+    n, p = X.shape
+    k = U.shape[1]
+    eng = ProjectionEngine(X)
+    M = W.T @ U
+    ref = V * s
+    Xm = eng.apply_operator(Wm)
+    np.random.seed(1234)
+    pinds = resample.task_permutations(co, nperm)
+    binds = resample.bootstraps(co, nboot)
+    res = eng.boot_phase(k, inds=eng.dev(binds, torch.int32), M=eng.dev(M), ref=eng.dev(ref), Xm=Xm,
+                         overlap_tail=overlap_tail)
+    ssq_p = eng.perm_phase(k, inds=eng.dev(pinds, torch.int32), M=eng.dev(M))
+    eng.join()
+    sd, ratio = eng.boot_finalize(res["S1"], res["S2"], nboot, num=eng.dev(ref))
+    torch.cuda.synchronize()
+    ssq_p, ssq_b, T, S1, S2, sd, ratio = (t.cpu().numpy() for t in
+                                          (ssq_p, res["ssq"], res["T"], res["S1"], res["S2"], sd, ratio))
+    live = s > 1e-10 * s.max()
+    G = X @ X.T
+    # permutation: s_hat^2[b, j] = a_bj^T G a_bj   (bootstrap_permutation.py:404-405)
+    a = _operators(M, pinds)
+    want = np.einsum("bij,il,blj->bj", a, G, a)
+    assert_close(ssq_p[:, live], want[:, live], 1e-10, 0, "perm s_hat^2 (Gram identity)")
+    assert np.all(np.abs(ssq_p[:, ~live]) <= 1e-18 * want.max())
+    # bootstrap: column norms (:623) and Tdistrib numerators (:633-634) the same way
+    a = _operators(M, binds)
+    want = np.einsum("bij,il,blj->bj", a, G, a)
+    assert_close(ssq_b[:, live], want[:, live], 1e-10, 0, "boot column norms^2 (Gram identity)")
+    wantT = np.einsum("ci,il,blj->bjc", Wm, G, a)
+    assert_close(T[:, live], wantT[:, live], 1e-9, 1e-11 * np.abs(wantT).max(), "Tdistrib numerators")
+    # voxel-local: every bootstrap's projection of a voxel subset, directly (:617-626, :695)
+    VS = np.einsum("iv,bij->bvj", X[:, sub], a)                  # (R, |sub|, k) = right_sv_sampled[:, sub]
+    d = VS - ref[sub]
+    scale = np.abs(VS).max()
+    assert_close(S1[sub], d.sum(0), 1e-9, 1e-11 * scale * nboot, "S1 (shifted first moment)")
+    assert_close(S2[sub], (d ** 2).sum(0), 1e-9, 1e-11 * scale ** 2 * nboot, "S2 (shifted second moment)")
+    assert_close(sd[sub][:, live], np.std(VS, axis=0)[:, live], 1e-9, 1e-13, "std_errs")
+    assert_close(ratio[sub][:, live], (ref[sub] / np.std(VS, axis=0))[:, live], 1e-8, 1e-10, "boot_ratios")
+    return eng
+
+
+def _subset(p, m=500, seed=3):
+    sub = np.random.RandomState(seed).choice(p, m, replace=False)
+    return np.unique(np.concatenate((sub, [0, 63, 64, 65, p // 2, p - 65, p - 64, p - 1])))
+
+
+def test_config2_bench_launch_shape_msplit_ge_2():
+    """BASELINE config 2 exactly as bench.py launches it: 60 x 200 000, 1000 + 1000 resamples in
+    one launch each.  At this shape the bootstrap kernel (K1br) runs two runs per latent
+    variable over 63 batch tiles (msplit = 2, an odd tile count): second-moment partials per
+    run, first moment from the summed operator by the first run only."""
+    co, X, W, Wm, U, s, V = _mct_problem((10, 10), 3, 200_000)
+    eng = _check_mct_phases(X, co, W, Wm, U, s, V, 1000, 1000, _subset(200_000))
+    plan = eng.plan(6, 1000, k2=6, boot=True)
+    assert plan["register_resident"] and plan["splits"] >= 2, plan      # the msplit >= 2 branch ran
+    assert plan["tiles"] == 63 and plan["tiles"] % plan["splits"] != 0, plan
+    assert eng.batch_size(6, 6, 1000) == 1000                           # one launch, like the bench
+    assert eng.plan(6, 1000, boot=False)["splits"] > 1
+
+
+@pytest.mark.parametrize("p,R", [(3001, 272), (3001, 1000), (130, 2000)])
+def test_k1br_splits_small_p(p, R):
+    """msplit up to tpl / 4 with few voxel tiles (want is large): tile counts that do not divide
+    by the number of runs, compared in full with direct NumPy."""
+    co, X, W, Wm, U, s, V = _mct_problem((10, 10), 3, p, seed=p)
+    eng = _check_mct_phases(X, co, W, Wm, U, s, V, R // 2 + 3, R, np.arange(p), overlap_tail=False)
+    plan = eng.plan(6, R, k2=6, boot=True)
+    assert plan["register_resident"] and plan["splits"] >= 4, plan
+    assert plan["tiles"] % plan["splits"] != 0, plan
+
+
+def test_config5_shape_lds_fed_kernels():
+    """BASELINE config 5's shape (mct 240 x 500 000, k = 12): the LDS-fed projection kernel with one
+    workgroup of ten (bootstrap, period 3, NH 3) / fourteen (permutation) waves per CU."""
+    co, X, W, Wm, U, s, V = _mct_problem((20, 20, 20, 20), 3, 500_000)
+    eng = _check_mct_phases(X, co, W, Wm, U, s, V, 112, 104, _subset(500_000, 300))
+    plan = eng.plan(12, 104, k2=12, boot=True)
+    assert not plan["register_resident"] and plan["voxel_tiles"] == 7813, plan
+
+
+def test_mct_k16_n128_no_spill_shape():
+    """An mct shape that used to run a spilling instance (LDS-fed bootstrap kernel, period 4:
+    k = 16, n = 128)."""
+    co, X, W, Wm, U, s, V = _mct_problem((8,) * 8, 2, 20_000, seed=8)
+    _check_mct_phases(X, co, W, Wm, U, s, V, 40, 72, _subset(20_000, 300))
+
+
+# ---------------------------------------------------------------------------
+# config 3: behaviour PLS 120 x 200 000, Y 120 x 8 (k = 48)
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def rb_problem():
+    co = np.array([[20] * 3, [20] * 3])
+    X = np.random.RandomState(0).randn(120, 200_000)
+    Y = np.random.RandomState(1).randn(120, 8)
+    obs = orc.observed("rb", X, co, Y=Y)
+    return co, X, Y, obs
+
+
+def test_config3_rb_bootstrap_full_batch_plus_ragged(rb_problem):
+    """135 bootstraps = one full batch of 125 items (24 GiB scratch limit) + a ragged one of 10,
+    through item_stats / item_fused2<4,64> / latent_kernel<3,1,1,8>."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    co, X, Y, obs = rb_problem
+    U, s, V = obs["U"], obs["s"], obs["V"]
+    nboot = 135
+    np.random.seed(77)
+    rt = ResampleTest._create("rb", X, Y, U, s.copy(), V, co, None, nperm=0, nboot=nboot,
+                              lvcorrs_orig=obs["lvcorrs"])
+    inds = rt.boot_debug_dict["indices"]
+    assert inds.shape == (nboot, 120)
+    # voxel-local statistics over all 135 bootstraps: the oracle on a voxel subset, same draws
+    sub = _subset(200_000, 250)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        ref = orc.bootstrap_test("rb", X[:, sub], Y, U, s, V[sub], co, None, nboot, lvcorrs_orig=obs["lvcorrs"],
+                                 sampler=orc.ReplaySampler(list(inds)), keep_right=False)
+    assert_close(rt.std_errs[sub], ref["std_errs"], 1e-8, 1e-13, "std_errs (voxel subset, all bootstraps)")
+    assert_close(rt.boot_ratios[sub], ref["boot_ratios"], 1e-8, 1e-10, "boot_ratios")
+    assert np.isfinite(rt.std_errs).all() and (rt.std_errs > 0).all()
+    # p-wide: LVcorr of single bootstraps through the oracle's direct form at full size
+    # (first / last of the full batch, first / last of the ragged one)
+    for b in (0, 124, 125, 134):
+        Xn, Yn = X[inds[b]], Y[inds[b]]
+        VS = orc.compute_corr(Xn, Yn, co).T @ U                     # :613, :620
+        lc = orc.compute_corr(Xn @ orc.normalize(VS), Yn, co)       # :623, :638-641
+        assert_close(rt.LVcorr[b], lc, 1e-8, 1e-11, f"LVcorr[{b}]")
+    z = 1.959963984540054
+    half = np.std(rt.LVcorr, axis=0) * z
+    assert_close(rt.conf_ints[0], obs["lvcorrs"] - half, 1e-12, 1e-14, "conf lo")
+
+
+def test_config3_rb_permutation(rb_problem):
+    """rb permutation phase at full size: project_kernel<1,0,0> with eight waves on the z-scored X
+    (n = 120).  Selected permutations against the direct form; counts against those values."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    co, X, Y, obs = rb_problem
+    U, s, V = obs["U"], obs["s"], obs["V"]
+    nperm = 530                                   # two device batches (512 + 18)
+    np.random.seed(78)
+    rt = ResampleTest._create("rb", X, Y, U, s.copy(), V, co, None, nperm=nperm, nboot=0)
+    perms = rt.perm_debug_dict["indices"]
+    s_list = rt.perm_debug_dict["s_list"]
+    assert s_list.shape == (nperm, 48) and np.isfinite(s_list).all()
+    for b in (0, 511, 512, 529):
+        VS = orc.compute_corr(X, Y[perms[b]], co).T @ U             # :338, :396, :404
+        assert_close(s_list[b], np.sqrt((VS ** 2).sum(0)), 1e-10, 0, f"s_hat[{b}]")
+    # sum_j s_hat_j^2 = ||R_b||_F^2 is p-free given the z-scored X: check every permutation
+    bounds = np.concatenate(([0], np.cumsum(co.reshape(-1))))
+    Xz = np.concatenate([np.nan_to_num(orc._zscore_cell(X[lo:hi])) / np.sqrt(hi - lo)
+                         for lo, hi in zip(bounds[:-1], bounds[1:])])
+    tot = np.zeros(nperm)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        Gc = Xz[lo:hi] @ Xz[lo:hi].T
+        Yp = Y[perms[:, lo:hi]]                                      # (R, n_c, b)
+        Yz = (Yp - Yp.mean(1, keepdims=True)) / Yp.std(1, keepdims=True) / np.sqrt(hi - lo)
+        tot += np.einsum("rib,ij,rjb->r", Yz, Gc, Yz)
+    assert_close((s_list ** 2).sum(1), tot, 1e-10, 0, "sum of s_hat^2 per permutation")
+    np.testing.assert_array_equal(rt.permute_ratio, (s_list >= s).sum(0) / (nperm + 1))
+
+
+# ---------------------------------------------------------------------------
+# config 4: multiblock split-half, k = 38, fused Gram gram_kernel<5,1,true>
+# ---------------------------------------------------------------------------
+def test_config4_mb_split_half_full_size():
+    from plspy_amd import split_half_resampling as sh
+    co = np.array([[20] * 3, [20] * 3])
+    X = np.random.RandomState(0).randn(120, 200_000)
+    Y = np.random.RandomState(1).randn(120, 8)
+    bscan = [1, 2]
+    S, lv = 12, 2
+    mask = orc.bscan_mask(co, bscan)
+    kw = dict(mctype=0, bscan=bscan, Xbscan=X[mask], Ybscan=Y[mask])
+    np.random.seed(41)
+    tt = sh.split_half_test_train("mb", X, Y, co, S, **kw)
+    np.random.seed(41)
+    res = sh.split_half("mb", X, Y, co, S, lv=lv, CI=0.95, **kw)
+    only = {0, S - 1}
+    okw = dict(mctype=0, bscan=bscan, Ybscan=Y[mask], lv=lv, only=only)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        np.random.seed(41)
+        ott = orc.split_half_both("mb", X, Y, co, S, which="tt", **okw)
+        np.random.seed(41)
+        osh = orc.split_half_both("mb", X, Y, co, S, which="sh", **okw)
+    assert tt["pls_s_train"].shape == (38, 38, S)
+    nl = 8                                 # leading latent variables (well separated on randn data)
+    d = np.arange(nl)
+    for i in sorted(only):
+        for key in ("pls_s_train", "pls_s_train_null"):
+            assert_close(tt[key][:, :, i], ott[key][:, :, i], 1e-9, 1e-10, f"{key}[{i}]")
+        for key in ("pls_s_test", "pls_s_test_null"):
+            assert_close(tt[key][d, d, i], ott[key][d, d, i], 1e-7, 1e-10, f"{key}[{i}] diag")
+            assert_close(np.abs(tt[key][:nl, :nl, i]), np.abs(ott[key][:nl, :nl, i]), 1e-6, 1e-9, f"{key}[{i}]")
+        for key in ("pls_dist_u", "pls_dist_v", "pls_dist_null_u", "pls_dist_null_v"):
+            assert_close(np.abs(res[key][:nl, :nl, i]), np.abs(osh[key][:nl, :nl, i]), 1e-6, 1e-9, f"{key}[{i}]")
+    for key, val in tt.items():
+        # (z of the two null latent variables of the rank-deficient task block is 0 / 0 here and
+        # noise / noise in the reference)
+        assert np.isfinite(np.asarray(val, dtype=float)[:36]).all(), key
+
+
+def test_config6_mb_bootstrap_full_size():
+    """Multiblock bootstrap (not a BASELINE config; SURVEY a12 on config 4's data): the two K4f passes
+    (row norms, projection) + K5 at n = 120, kr = 38."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    co = np.array([[20] * 3, [20] * 3])
+    X = np.random.RandomState(0).randn(120, 200_000)
+    Y = np.random.RandomState(1).randn(120, 8)
+    bscan = [1, 2]
+    obs = orc.observed("mb", X, co, Y=Y, mctype=0, bscan=bscan)
+    U, s, V = obs["U"], obs["s"], obs["V"]
+    nboot = 40
+    np.random.seed(5)
+    rt = ResampleTest._create("mb", X, Y, U, s.copy(), V, co, 0, nperm=0, nboot=nboot, bscan=bscan,
+                              Xbscan=obs["Xbscan"], Ybscan=obs["Ybscan"], lvcorrs_orig=obs["lvcorrs"],
+                              Tvsc_orig=obs["Tvsc_orig"])
+    draws = rt.boot_debug_dict["indices"]
+    n = 120
+    ti, bi = draws[:, :n], draws[:, n:]
+    live = s > 1e-10 * s.max()
+    for b in (0, nboot - 1):
+        M = orc.create_multiblock(X[ti[b]], co, "mb", bscan, 0, Xbscan=obs["Xbscan"][bi[b]],
+                                  Ybscan=obs["Ybscan"][bi[b]])       # :610
+        Vh = orc.normalize(M.T @ U)                                   # :620, :623
+        lc = orc.compute_corr(obs["Xbscan"][bi[b]] @ Vh, obs["Ybscan"][bi[b]], co[:, bscan])
+        assert_close(rt.LVcorr[b][:, live], lc[:, live], 1e-8, 1e-11, f"mb LVcorr[{b}]")
+        Td = orc.group_condition_means(orc.calculate_smeanmat(X[ti[b]], co, 0) @ Vh, co)
+        assert_close(rt.boot_debug_dict["Tdistrib"][b][:, live], Td[:, live], 1e-8, 1e-11, f"mb Tdistrib[{b}]")
+    assert np.isfinite(rt.std_errs).all()

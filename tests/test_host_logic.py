@@ -117,3 +117,16 @@ def test_shard_bounds_cover():
             assert all(b[i][1] == b[i + 1][0] for i in range(n - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_assert_close_rejects_non_finite_mismatch():
+    """The parity helper must not let a NaN / inf from a kernel pass against a finite
+    expected value (and must still accept matching non-finite entries)."""
+    import pytest
+    from tests._util import assert_close
+    assert_close([1.0, 2.0], [1.0, 2.0 + 1e-13], 1e-10)
+    assert_close([np.nan, 1.0, np.inf, -np.inf], [np.nan, 1.0, np.inf, -np.inf], 1e-10)
+    for got, want in (([np.nan, 1.0], [2.0, 1.0]), ([2.0, 1.0], [np.nan, 1.0]), ([np.inf, 1.0], [2.0, 1.0]),
+                      ([np.inf], [-np.inf]), ([1.0], [1.1])):
+        with pytest.raises(AssertionError):
+            assert_close(got, want, 1e-10)
