@@ -31,21 +31,49 @@ def test_two_ranks_match_one(tmp_path):
         np.testing.assert_allclose(two[key], want, rtol=1e-10, atol=1e-12, err_msg=key)
 
 
-def test_bench_two_ranks_verified():
-    """bench.py's N > 1 path (the driver's scaling run) as two gloo ranks on the test box's
-    one device: the step that overlaps the bootstrap's collectives with the permutation kernel
-    must hand rank 0 the same numbers as a single-rank pass over the whole job (--verify)."""
+def _bench_line(proc):
     import json
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert "[verify] 2 rank(s), strong job" in proc.stderr and "[verify] 2 rank(s), weak job" in proc.stderr
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["backend"] == "gloo"
+    assert line["scaling"] == "strong" and line["value"] == line["strong"]["value"] > 0
+    assert line["strong"]["job"].startswith("1000 perm + 1000 boot in total, 500 + 500")
+    assert line["weak"]["job"].startswith("2000 perm + 2000 boot in total, 1000 + 1000")
+    assert line["roofline"]["bound"] == "mfma" and line["roofline"]["resamples_per_launch"] == 500
+    assert line["cpu_baseline"] is None
+    return line
+
+
+def test_bench_self_launch_two_ranks_verified():
+    """`python bench.py --gpus 2` exactly as the driver types it for N = 1 -- no launcher, no
+    RANK / WORLD_SIZE in the environment: the script starts its own two ranks (gloo here, on the
+    test box's one device; RCCL on a multi-GPU node).  Both jobs (strong: the fixed 1000 + 1000
+    sharded; weak: 1000 + 1000 per rank) must hand rank 0 the same numbers as a single-rank pass
+    over the whole job (--verify), with the bootstrap's collectives overlapping the permutation
+    kernel."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                            "MASTER_PORT")}
+    env["PLSR_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--verify"]
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    _bench_line(proc)
+
+
+def test_bench_under_launcher_weak_value():
+    """The other start the contract names: under torch.distributed.run; --scaling weak makes the
+    per-GPU-fixed job the headline value."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, PLSR_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--verify"]
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--scaling", "weak"]
     proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert proc.returncode == 0, proc.stderr[-3000:]
-    assert "[verify] 2 rank(s)" in proc.stderr
+    import json
     line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    assert line["roofline"]["bound"] == "mfma" and line["cpu_baseline"] is None
+    assert line["scaling"] == "weak" and line["value"] == line["weak"]["value"] > 0
+    assert line["roofline"]["resamples_per_launch"] == 1000
