@@ -176,7 +176,25 @@ int plsr_gram_batch(const double *d_X, int64_t x_item_stride, int64_t ldx, int64
  * k <= 64.
  */
 int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t ld, int32_t off,
-                    int32_t k, int32_t count, double *d_evals, double *d_evecs, void *stream);
+                    int32_t k, int32_t count, double *d_evals, double *d_evecs,
+                    const double *d_init, int32_t relative, void *stream);
+/*
+ * (continued) d_init: NULL, or [count][k][k] -- the rotations are then applied to the columns
+ * of d_init[item] instead of the identity, so d_evecs = d_init * J: the basis accumulated over
+ * refinement passes (must not alias d_evecs).  relative != 0: the block is the Gram of rows
+ * that are already nearly orthogonal with graded norms (a refinement pass); no rotation is
+ * skipped for being small against the largest diagonal entry, which makes the eigenvalues
+ * RELATIVELY accurate -- LAPACK-grade small singular values for _run_pls's np.linalg.svd
+ * (class_functions.py:98-123), which eig of a once-formed Gram cannot give (it squares the
+ * condition number).
+ *
+ * plsr_rotate_rows: d_rows_out[item][off + j][:] = sum_i d_U[item][i][j] * d_rows_in[item][off + i][:]
+ * for j < k; rows outside [off, off + k) are copied.  The operator rows of a decomposed block in
+ * its eigenvector basis: input of the next refinement pass's Gram, and after the last pass the
+ * operator of the back-projection V s = (rows_out @ X)^T.
+ */
+int plsr_rotate_rows(const double *d_U, const double *d_rows_in, double *d_rows_out, int32_t items,
+                     int32_t m, int32_t n, int32_t off, int32_t k, void *stream);
 
 /*
  * ---- K3: row gather + per-cell z-score --------------------------------------

@@ -48,7 +48,7 @@ static inline int check_launch() {
   return PLSR_OK;
 }
 
-extern "C" int plsr_abi_version(void) { return 1; }
+extern "C" int plsr_abi_version(void) { return 2; }
 extern "C" int plsr_last_hip_error(void) { return g_last_hip; }
 
 extern "C" const char *plsr_strerror(int code) {
@@ -705,11 +705,22 @@ extern "C" int plsr_gram_batch(const double *d_X, int64_t x_item_stride, int64_t
 
 extern "C" int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t ld, int32_t off,
                                int32_t k, int32_t count, double *d_evals, double *d_evecs,
-                               void *stream) {
+                               const double *d_init, int32_t relative, void *stream) {
   if (!d_G || !d_evals || !d_evecs || count <= 0 || k <= 0 || ld < off + k) return PLSR_EINVAL;
   if (k > EIG_MAX) return PLSR_EUNSUPPORTED;
+  if (d_init == d_evecs) return PLSR_EINVAL;          // the output is written in sorted column order
   hipLaunchKernelGGL(eigh_kernel, dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream, d_G,
-                     item_stride, ld, off, k, count, d_evals, d_evecs, 30);
+                     item_stride, ld, off, k, count, d_evals, d_evecs, 30, d_init, (int)(relative != 0));
+  return check_launch();
+}
+
+extern "C" int plsr_rotate_rows(const double *d_U, const double *d_rows_in, double *d_rows_out, int32_t items,
+                                int32_t m, int32_t n, int32_t off, int32_t k, void *stream) {
+  if (!d_U || !d_rows_in || !d_rows_out || items <= 0 || m <= 0 || n <= 0 || off < 0 || k <= 0 || off + k > m ||
+      d_rows_in == d_rows_out)
+    return PLSR_EINVAL;
+  hipLaunchKernelGGL(rotate_rows_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256), (unsigned)items), dim3(256), 0,
+                     (hipStream_t)stream, d_U, d_rows_in, d_rows_out, m, n, off, k);
   return check_launch();
 }
 

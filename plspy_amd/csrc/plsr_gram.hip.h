@@ -314,9 +314,16 @@ __global__ __launch_bounds__(256) void ops_rows_kernel(const double *rows, doubl
 // ---------------------------------------------------------------------------
 constexpr int EIG_MAX = 64;
 
+// `init` (may be null): per item a k x k matrix V0 whose columns the rotations are applied to
+// instead of the identity, so the result is V0 * J -- the accumulated basis of a refinement
+// pass.  `relative`: the Gram was formed from rows that are already nearly orthogonal with
+// graded norms (a refinement pass: G = D A D, A close to I, entry errors ~ eps d_i d_j), where
+// two-sided Jacobi is RELATIVELY accurate (Demmel & Veselic) as long as no rotation is skipped
+// for being small in absolute terms -- the noise clause below is then switched off.
 __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t item_stride, int ld,
                                                   int off, int k, int count, double *evals,
-                                                  double *evecs, int max_sweeps) {
+                                                  double *evecs, int max_sweeps, const double *init,
+                                                  int relative) {
   __shared__ double As[EIG_MAX * (EIG_MAX + 1)];
   __shared__ double Vs[EIG_MAX * (EIG_MAX + 1)];
   __shared__ double cs[EIG_MAX], sn[EIG_MAX];
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t it
     const int r = e / k, c = e % k;
     // symmetrise: the Gram is symmetric up to rounding of two summation orders
     As[r * LD + c] = 0.5 * (G[(int64_t)r * ld + c] + G[(int64_t)c * ld + r]);
-    Vs[r * LD + c] = r == c ? 1.0 : 0.0;
+    Vs[r * LD + c] = init ? init[(int64_t)item * k * k + e] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t it
     double dmax = 0.0;
     for (int r = lane; r < k; r += 64) dmax = fmax(dmax, fabs(As[r * LD + r]));
     for (int sft = 32; sft > 0; sft >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, sft));
-    const double noise = 8.9e-16 * dmax;
+    const double noise = relative ? 0.0 : 8.9e-16 * dmax;
     double worst = 0.0;
     for (int e = lane; e < k * k; e += 64) {
       const int r = e / k, c = e % k;
@@ -422,6 +429,29 @@ __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t it
     evals[(int64_t)item * k + rank] = lam;
     for (int r = 0; r < k; ++r) evecs[((int64_t)item * k + r) * k + rank] = Vs[r * LD + lane];
   }
+}
+
+// rows_out[item][off + j][:] = sum_i U[item][i][j] * rows_in[item][off + i][:]   (j < k): the
+// operator rows of a decomposition's block expressed in its eigenvector basis -- the next
+// refinement pass forms the Gram of THESE rows, and after the last pass they are the operator
+// of the back-projection VS = rows_out @ X.  Rows outside the block are copied.
+__global__ void rotate_rows_kernel(const double *U, const double *rows_in, double *rows_out, int m, int n,
+                                   int off, int k) {
+  const int item = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * n) return;
+  const int r = e / n, c = e % n;
+  const double *in = rows_in + (int64_t)item * m * n;
+  double acc;
+  if (r < off || r >= off + k) {
+    acc = in[e];
+  } else {
+    const double *u = U + (int64_t)item * k * k;
+    const int j = r - off;
+    acc = 0.0;
+    for (int i = 0; i < k; ++i) acc = fma(u[i * k + j], in[(int64_t)(off + i) * n + c], acc);
+  }
+  rows_out[(int64_t)item * m * n + e] = acc;
 }
 
 }  // namespace plsr

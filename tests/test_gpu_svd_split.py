@@ -122,3 +122,136 @@ def test_full_pls_with_split_half():
     for key in ("pls_rep_mean_u", "pls_rep_mean_v", "pls_null_mean_u", "pls_rep_z_u"):
         assert_close(np.array(res.pls_repro_sh[key]), fx["sh_" + key][: fx["lv"]], 1e-6, 1e-9, key)
     assert_close(np.array(res.pls_repro_tt["z"])[: len(live)], fx["tt_z"][: len(live)], 1e-6, 1e-9, "tt z")
+
+
+# ---------------------------------------------------------------------------
+# LAPACK-grade relative accuracy of the thin SVD on ill-conditioned blocks
+# ---------------------------------------------------------------------------
+def _hestenes_longdouble(M):
+    """Singular values of M (k x p) by one-sided Jacobi in 80-bit arithmetic: the yardstick
+    both LAPACK and the device are measured against (relative accuracy ~1e-18 * sqrt(p))."""
+    A = np.asarray(M, dtype=np.longdouble).copy()
+    k = A.shape[0]
+    for _ in range(60):
+        worst = 0.0
+        for p in range(k - 1):
+            for q in range(p + 1, k):
+                a, b, g = A[p] @ A[p], A[q] @ A[q], A[p] @ A[q]
+                if a == 0 or b == 0:
+                    continue
+                r = abs(g) / np.sqrt(a * b)
+                worst = max(worst, float(r))
+                if r > 1e-19:
+                    tau = (b - a) / (2 * g)
+                    t = (1.0 if tau >= 0 else -1.0) / (abs(tau) + np.sqrt(1 + tau * tau))
+                    c = 1 / np.sqrt(1 + t * t)
+                    s = t * c
+                    Ap = A[p].copy()
+                    A[p] = c * Ap - s * A[q]
+                    A[q] = s * Ap + c * A[q]
+        if worst < 1e-18:
+            break
+    return np.sort(np.sqrt(np.array([r @ r for r in A], dtype=np.longdouble)))[::-1].astype(float)
+
+
+def _graded(k, p, ratio, seed):
+    rs = np.random.RandomState(seed)
+    U0, _ = np.linalg.qr(rs.randn(k, k))
+    V0, _ = np.linalg.qr(rs.randn(p, k))
+    sig = np.logspace(0, np.log10(ratio), k) * 37.0
+    return (U0 * sig) @ V0.T
+
+
+@pytest.mark.parametrize("k,ratio", [(6, 1e-3), (6, 1e-7), (38, 1e-5), (48, 1e-7), (12, 1e-5)])
+def test_thin_svd_graded_spectrum_relative_accuracy(eng_factory, k, ratio):
+    """north_star: "fp64 singular values match numpy.linalg.svd to 1e-10 rel".  The block handed to
+    LAPACK and to the device is the SAME fp64 matrix (rows = identity), with singular values
+    spread over 3 / 5 / 7 decades and randomly oriented singular vectors (the small ones are
+    hidden behind cancellation, as in real data).  Every singular value -- not only the leading
+    ones -- must match an 80-bit reference to 1e-10 relative, and NumPy to 1e-10 plus NumPy's own
+    distance from that reference (LAPACK's dgesdd is only normwise stable: at s_k / s_1 = 1e-7 its
+    values are themselves off by up to ~1e-10 relative).  Eig of a once-formed Gram (round 1) gave
+    1e-8 at a ratio of 1e-4 and deflated everything below 3e-7 s_max to 0."""
+    p = 5000
+    M = _graded(k, p, ratio, seed=k)
+    eng = eng_factory(M)
+    U, s, V = eng.thin_svd(np.eye(k))
+    Ul, sl, Vlt = np.linalg.svd(M, full_matrices=False)
+    truth = _hestenes_longdouble(M)
+    assert np.all(s > 0), "no live latent variable may be deflated"
+    rel_truth = np.abs(s - truth) / truth
+    lapack_err = np.abs(sl - truth) / truth
+    assert rel_truth.max() < 1e-10, f"vs 80-bit reference: {rel_truth.max():.2e}"
+    rel_np = np.abs(s - sl) / sl
+    assert np.all(rel_np < 1e-10 + lapack_err), f"vs numpy {rel_np.max():.2e} (numpy vs reference {lapack_err.max():.2e})"
+    # vectors after sign alignment: 1e-8, widened by the conditioning of each vector
+    # (a perturbation of eps s_1 turns vector i by ~eps s_1 / gap_i; LAPACK's carry the same)
+    sign = np.sign(np.sum(U * Ul, axis=0))
+    tol = 1e-8 + 50 * np.finfo(float).eps * sl[0] / sl
+    assert np.all(np.abs(U * sign - Ul).max(axis=0) < tol), np.abs(U * sign - Ul).max(axis=0) / tol
+    assert np.all(np.abs(V * sign - Vlt.T).max(axis=0) < tol), np.abs(V * sign - Vlt.T).max(axis=0) / tol
+    np.testing.assert_allclose(U.T @ U, np.eye(k), atol=1e-13)
+    np.testing.assert_allclose(V.T @ V, np.eye(k), atol=1e-8 * max(1.0, 1e-7 / ratio))
+
+
+def test_thin_svd_operator_times_data_conditioning_bound(eng_factory):
+    """The same through a non-trivial operator (rows = Q, X = Q^T M): the product is now rounded
+    differently on the host and on the device, which moves a singular value by up to ~eps s_1 --
+    the problem's own conditioning; the comparison allows exactly that and nothing more."""
+    k, p = 12, 5000
+    M = _graded(k, p, 1e-6, seed=3)
+    Q, _ = np.linalg.qr(np.random.RandomState(9).randn(k + 5, k + 5))
+    Q = Q[:k]                                             # k x n, orthonormal rows
+    X = Q.T @ M                                           # n x p
+    eng = eng_factory(X)
+    U, s, V = eng.thin_svd(Q)
+    sl = np.linalg.svd(Q @ X, compute_uv=False)
+    assert np.all(np.abs(s - sl) < 1e-10 * sl + 64 * k * np.finfo(float).eps * sl[0])
+
+
+def test_thin_svd_null_space_is_deflated_at_reference_threshold(eng_factory):
+    """Rank-deficient centring (mctype 0, two groups: 4 of 6 live): the null values come out as exact
+    zeros with zero vectors; a REAL latent variable 1e-6 times the largest one stays live."""
+    from plspy_amd import operators
+    co = np.array([[10] * 3, [10] * 3])
+    rs = np.random.RandomState(0)
+    X = rs.randn(60, 3000)
+    W = operators.mean_centre_operator(co, 0)
+    U, s, V = eng_factory(X).thin_svd(W)
+    sl = np.linalg.svd(W @ X, compute_uv=False)
+    assert np.all(s[4:] == 0) and np.all(V[:, 4:] == 0)
+    np.testing.assert_allclose(s[:4], sl[:4], rtol=1e-12)
+    # a genuine but tiny latent variable: scale one cell-mean direction down by 1e-6
+    M = W @ X
+    Uw, sw, Vwt = np.linalg.svd(M, full_matrices=False)
+    sw2 = sw.copy()
+    sw2[3] = 1e-6 * sw[0]
+    M2 = (Uw * sw2) @ Vwt
+    U2, s2, V2 = eng_factory(M2).thin_svd(np.eye(6))
+    np.testing.assert_allclose(s2[:4], np.linalg.svd(M2, compute_uv=False)[:4], rtol=1e-9)
+    assert s2[3] > 0 and np.all(s2[4:] == 0)
+
+
+@pytest.mark.parametrize("k", [5, 24, 48])
+def test_eigh_relative_mode_on_graded_gram(eng_factory, k):
+    """plsr_eigh_batch(relative = 1, init = V0): on G = D A D (A near I, D graded over 12 decades)
+    every eigenvalue is relatively accurate and the returned basis is V0 @ J."""
+    import torch
+    rs = np.random.RandomState(k)
+    eng = eng_factory(rs.randn(4, 8))
+    Q, _ = np.linalg.qr(rs.randn(k + 3, k + 3))
+    d = np.logspace(0, -6, k)
+    B = d[:, None] * (Q[:k] + 1e-3 * rs.randn(k, k + 3))          # nearly orthogonal rows, graded norms
+    G = np.zeros((1, 64, 64))
+    G[0, :k, :k] = B @ B.T
+    V0, _ = np.linalg.qr(rs.randn(k, k))
+    ev, vec = eng.eigh(torch.as_tensor(G, device=eng.device), 0, k,
+                       init=torch.as_tensor(V0[None].copy(), device=eng.device), relative=True)
+    ev, vec = ev.cpu().numpy()[0], vec.cpu().numpy()[0]
+    truth = _hestenes_longdouble(B) ** 2
+    assert np.max(np.abs(ev - truth) / truth) < 1e-12
+    J = V0.T @ vec                                                  # the pure rotation
+    np.testing.assert_allclose(J.T @ J, np.eye(k), atol=1e-13)
+    Gk = G[0, :k, :k]
+    resid = J.T @ Gk @ J - np.diag(ev)
+    assert np.all(np.abs(resid) <= 1e-13 * np.sqrt(np.outer(ev, ev)) + 1e-300)

@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.plsr_abi_version() == 1
+    assert lib.plsr_abi_version() == 2
     assert lib.plsr_strerror(0) == b"ok"
 
 
