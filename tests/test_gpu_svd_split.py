@@ -253,5 +253,6 @@ def test_eigh_relative_mode_on_graded_gram(eng_factory, k):
     J = V0.T @ vec                                                  # the pure rotation
     np.testing.assert_allclose(J.T @ J, np.eye(k), atol=1e-13)
     Gk = G[0, :k, :k]
-    resid = J.T @ Gk @ J - np.diag(ev)
-    assert np.all(np.abs(resid) <= 1e-13 * np.sqrt(np.outer(ev, ev)) + 1e-300)
+    # (normwise only: forming J^T G J in fp64 here already costs eps |G| per entry; the relative
+    # accuracy is what the eigenvalue comparison above establishes)
+    np.testing.assert_allclose(J.T @ Gk @ J, np.diag(ev), atol=1e-13 * np.abs(Gk).max())
