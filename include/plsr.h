@@ -195,6 +195,16 @@ int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t ld, int32_t 
  */
 int plsr_rotate_rows(const double *d_U, const double *d_rows_in, double *d_rows_out, int32_t items,
                      int32_t m, int32_t n, int32_t off, int32_t k, void *stream);
+/*
+ * Last step of the thin SVD, on the device (no host round trip between the decomposition and the
+ * resampling phases): d_lam [k] eigenvalues of the final pass (descending), d_cur [k][n] = U^T rows.
+ *   d_s[i]            = sqrt(lam_i), or 0 for a null latent variable: s_i <= max(abs_tol, rel_tol * s_0)
+ *                       (abs_tol = the reference's 1e-12, bootstrap_permutation.py:295)
+ *   d_rows_out[i]     = cur[i]        (0 if null):  rows_out[:k] @ X = (V s)^T   (class_functions.py:122-123)
+ *   d_rows_out[k + i] = cur[i] / s_i  (0 if null):  rows_out[k:] @ X =  V^T
+ */
+int plsr_svd_finish(const double *d_lam, const double *d_cur, int32_t k, int32_t n, double abs_tol,
+                    double rel_tol, double *d_s, double *d_rows_out, void *stream);
 
 /*
  * ---- K3: row gather + per-cell z-score --------------------------------------

@@ -44,6 +44,7 @@ SIGNATURES = {
     "plsr_gram_batch": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "plsr_gather_zscore": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "plsr_eigh_batch": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "plsr_svd_finish": (c_i32, [c_vp, c_vp, c_i32, c_i32, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp]),
     "plsr_rotate_rows": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "plsr_item_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32]),
     "plsr_item_fused": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32,

@@ -94,8 +94,14 @@ class _ResampleTestPLS(ResampleTest):
     def __init__(self, X, Y, U, s, V, cond_order, mctype, contrast=None, preprocess=None,
                  nperm=1000, nboot=1000, bscan=None, Xbscan=None, Ybscan=None,
                  lvcorrs_orig=None, Tvsc_orig=None, CI=0.95, engine=None, keep_right_sv=False,
-                 _pls_alg=None):
+                 _pls_alg=None, _observed=None):
         self.pls_alg = _pls_alg or self.pls_alg
+        # _observed (private, from the PLS classes): the observed decomposition as it sits on the
+        # device -- dict(k, U (k, k), VSt (k, p) = (V s)^T, Xm (cells, p) cell means, host() ->
+        # (U, s, V) NumPy once downloaded, XV() -> X @ V NumPy, Tvsc_orig() -> its cell means).
+        # With it the phases are enqueued without waiting for U / s / V on the host; the host
+        # arrays U, s, V may then be None.
+        self._obs = _observed
         self.CI = CI
         self._cond_order = np.asarray(cond_order)
         self._mctype = mctype
@@ -126,10 +132,16 @@ class _ResampleTestPLS(ResampleTest):
         # kernel; host post-processing follows in the reference's order.
         finish_perm = finish_boot = None
         if task:
+            launch_perm = tail_boot = None
             if nperm > 0:
-                finish_perm = self._perm_mct_start(U, s, nperm)
+                launch_perm, finish_perm = self._perm_mct_start(U, s, nperm)
             if nboot > 0:
-                finish_boot = self._bootstrap_test_start(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
+                tail_boot, finish_boot = self._bootstrap_test_start(U, s, V, nboot, Tvsc_orig, CI, keep_right_sv)
+            # everything is enqueued before the host waits for anything
+            if launch_perm is not None:
+                launch_perm()
+            if tail_boot is not None:
+                tail_boot()
         if nperm > 0:
             if task:
                 self.permute_ratio, self.stepdown_ratio, self.perm_debug_dict = finish_perm()
@@ -167,8 +179,8 @@ class _ResampleTestPLS(ResampleTest):
     # shared pieces
     # ------------------------------------------------------------------
     @staticmethod
-    def _run_perm(eng, k, niter, inds=None, M=None, cols=None, beh=None):
-        """Shard the phase's resamples, run the permutation kernel, gather."""
+    def _run_perm_device(eng, k, niter, inds=None, M=None, cols=None, beh=None):
+        """Shard the phase's resamples, run the permutation kernel, gather (device tensor)."""
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
         if beh is not None:
@@ -179,7 +191,11 @@ class _ResampleTestPLS(ResampleTest):
         else:
             ssq = eng.perm_phase(k, inds=inds[lo:hi], M=M)
         (ssq,), _ = dist.exchange([ssq], [], niter)
-        return ssq.cpu().numpy()
+        return ssq
+
+    @classmethod
+    def _run_perm(cls, eng, k, niter, **kw):
+        return cls._run_perm_device(eng, k, niter, **kw).cpu().numpy()
 
     @staticmethod
     def _ratios(s_hat, s_ref, step_ref, niter):
@@ -198,20 +214,35 @@ class _ResampleTestPLS(ResampleTest):
     def _perm_mct_start(self, U, s, niter, threshold=1e-12):
         """bootstrap_permutation.py:266-464 for mct and cst (cst: cell means
         projected on the normalised contrasts, no threshold on s_hat, :429-433).
-        Draws the indices now; the returned callable runs the kernel and the
-        host summary."""
+        Draws the indices now; returns (launch, finish): launch() enqueues the kernel and the
+        download of its result, finish() waits for it and does the host summary."""
         eng = self._engine
-        Uq = np.asarray(U, dtype=float) if self._C is None else self._C
-        k = Uq.shape[1]
-        s[np.abs(s) < threshold] = 0            # in place, like the reference (:295, quirk Q1)
+        obs = self._obs if self._C is None else None
+        if obs is not None:
+            k = obs["k"]
+            # M = W^T U (n x k) where U lives:  (U^T W)^T, a layout copy of k x n numbers
+            Wd = eng.dev(np.ascontiguousarray(self._W, dtype=np.float64))
+            M = eng.rotate_rows(obs["U"][None], Wd[None])[0].t().contiguous()
+        else:
+            Uq = np.asarray(U, dtype=float) if self._C is None else self._C
+            k = Uq.shape[1]
+            s[np.abs(s) < threshold] = 0        # in place, like the reference (:295, quirk Q1)
+            M = self._W.T @ Uq                  # n x k:  VS = X^T (P^T W^T U)
         inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
-        M = self._W.T @ Uq                      # n x k:  VS = X^T (P^T W^T U)
+        pending = []
+
+        def launch():
+            pending.append(eng.fetch_async([self._run_perm_device(eng, k, niter, inds=inds, M=M)]))
 
         def finish():
-            s_hat = np.sqrt(self._run_perm(eng, k, niter, inds=inds, M=M))
+            s_obs = s
+            if obs is not None:
+                _, s_obs, _ = obs["host"]()
+                s_obs[np.abs(s_obs) < threshold] = 0        # (:295, Q1) on the array the caller keeps
+            s_hat = np.sqrt(pending[0].get()[0])
             if self._C is None:
                 s_hat[np.abs(s_hat) < threshold] = 0    # :436
-            ratio, step = self._ratios(s_hat, s, np.copy(s), niter)
+            ratio, step = self._ratios(s_hat, s_obs, np.copy(s_obs), niter)
             total = np.sum(s_hat ** 2, axis=1)
             debug = {
                 "s_list": s_hat,
@@ -222,10 +253,12 @@ class _ResampleTestPLS(ResampleTest):
                 "indices": inds,
             }
             return ratio, step, debug
-        return finish
+        return launch, finish
 
     def _perm_mct(self, U, s, niter, threshold=1e-12):
-        return self._perm_mct_start(U, s, niter, threshold)()
+        launch, finish = self._perm_mct_start(U, s, niter, threshold)
+        launch()
+        return finish()
 
     def _draw_behaviour_perms(self, Ysrc, niter, with_task):
         """Row permutations of the behaviour block (and, for multiblock, the task
@@ -344,57 +377,82 @@ class _ResampleTestPLS(ResampleTest):
     # bootstrap test (mct)
     # ------------------------------------------------------------------
     def _bootstrap_test(self, U, s, V, niter, Tvsc_orig, CI, keep_right_sv):
-        return self._bootstrap_test_start(U, s, V, niter, Tvsc_orig, CI, keep_right_sv)()
+        tail, finish = self._bootstrap_test_start(U, s, V, niter, Tvsc_orig, CI, keep_right_sv)
+        tail()
+        return finish()
 
     def _bootstrap_test_start(self, U, s, V, niter, Tvsc_orig, CI, keep_right_sv):
         """bootstrap_permutation.py:467-766 for mct and cst, streaming form.  cst:
         the projection is on the normalised contrasts (VS = permuted.T @ C, :620
         with U = C) and boot_ratios = V / std_errs (:703).  Draws the indices and
-        enqueues the kernels now (reductions on the engine's tail stream); the
-        returned callable joins and does the host summary."""
+        enqueues the kernels now (reductions on the engine's tail stream).  Returns (tail,
+        finish): tail() enqueues the exchange, the final statistics and their download (call it
+        after whatever should overlap the reductions has been enqueued), finish() waits and
+        does the host summary."""
         eng = self._engine
         co = self._cond_order
-        U = np.asarray(U, dtype=float) if self._C is None else self._C
-        k = U.shape[1]
-        V = np.asarray(V, dtype=float)
+        obs = self._obs if self._C is None else None
         rank, nranks = dist.world()
         inds = self._draw_on_rank0(lambda: resample.bootstraps(co, niter))
         lo, hi = dist.shard_bounds(niter, rank, nranks)
-        M = self._W.T @ U
         Wm = operators.cell_mean_operator(co)
-        Xm = eng.apply_operator(Wm)                   # k x p cell means of X, on device
-        # observed VS (shift of the moment sums and numerator of the ratios):
-        # X_mc.T @ U = V s for mct; R.T @ C = V for cst
-        ref = V * s if self._C is None else V
+        if obs is not None:
+            k = obs["k"]
+            Wd = eng.dev(np.ascontiguousarray(self._W, dtype=np.float64))
+            M = eng.rotate_rows(obs["U"][None], Wd[None])[0].t().contiguous()     # W^T U, on the device
+            ref = obs["VSt"].t().contiguous()            # observed VS = V s (p x k): a layout copy
+            Xm = obs["Xm"]
+        else:
+            U = np.asarray(U, dtype=float) if self._C is None else self._C
+            k = U.shape[1]
+            V = np.asarray(V, dtype=float)
+            M = self._W.T @ U
+            Xm = eng.apply_operator(Wm)                   # k x p cell means of X, on device
+            # observed VS (shift of the moment sums and numerator of the ratios):
+            # X_mc.T @ U = V s for mct; R.T @ C = V for cst
+            ref = eng.dev(V * s if self._C is None else V)
         res = eng.boot_phase(k, inds=inds[lo:hi], M=M, ref=ref, Xm=Xm, dump=keep_right_sv,
                              overlap_tail=True)
-        return lambda: self._bootstrap_test_finish(res, inds, niter, ref, V, Tvsc_orig, CI, keep_right_sv)
+        pending = []
 
-    def _bootstrap_test_finish(self, res, inds, niter, ref, V, Tvsc_orig, CI, keep_right_sv):
+        def tail():
+            eng.join()
+            per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
+            per, (S12,) = dist.exchange(per, [res["S12"]], niter)
+            sd, ratio = eng.boot_finalize(S12[0], S12[1], niter, num=ref)  # :695, :701
+            pending.append(eng.fetch_async([sd, ratio] + list(per)))
+
+        def finish():
+            Vh = V
+            if obs is not None:
+                _, _, Vh = obs["host"]()
+            got = pending[0].get()
+            return self._bootstrap_test_finish(got[0], got[1], got[2:], inds, Vh, Tvsc_orig, CI, keep_right_sv)
+        return tail, finish
+
+    def _bootstrap_test_finish(self, std_errs, boot_ratios, per, inds, V, Tvsc_orig, CI, keep_right_sv):
         eng = self._engine
-        eng.join()
-        per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
-        per, (S12,) = dist.exchange(per, [res["S12"]], niter)
-        sd, ratio = eng.boot_finalize(S12[0], S12[1], niter, num=ref)  # :695, :701
-        std_errs = sd.cpu().numpy()
-        boot_ratios = ratio.cpu().numpy()
-
         # Tdistrib[i] = cell means of X @ normalize(VS_i)  (:623, :633-634)
-        norms = np.sqrt(per[0].cpu().numpy())                         # R x k
-        T = per[1].cpu().numpy()                                      # R x k(lv) x k(cell)
+        norms = np.sqrt(per[0])                                       # R x k
+        T = per[1]                                                    # R x k(lv) x k(cell)
         with np.errstate(divide="ignore", invalid="ignore"):
             Td = np.where(norms[:, :, None] != 0, T / norms[:, :, None], 0.0)
         Tdistrib = np.transpose(Td, (0, 2, 1))                        # R x cell x lv
         z = norm.ppf(1 - (1 - CI) / 2)                                # :709
         half = np.std(Tdistrib, axis=0) * z                           # :715-716
+        if callable(Tvsc_orig):
+            Tvsc_orig = Tvsc_orig()
         conf_int = (Tvsc_orig - half, Tvsc_orig + half)               # :717
 
         # left_sv_sampled[i] = permuted_i @ V = W P_i (X V)   (:617, :631) -- p-free
-        XV = eng.latents(V)                                           # X @ V on the device (K5, one item)
+        if self._obs is not None and self._C is None:
+            XV = self._obs["XV"]()                                    # already formed for X_latent
+        else:
+            XV = eng.latents(V)                                       # X @ V on the device (K5, one item)
         left = self._W @ XV[inds]                                     # (c,r)(b,r,k) -> b,c,k
         debug = {
             "left_sv_sampled": left,
-            "right_sv_sampled": per[2].cpu().numpy() if keep_right_sv else None,
+            "right_sv_sampled": per[2] if keep_right_sv else None,
             "indices": inds,
             "Tdistrib": Tdistrib,
         }

@@ -724,6 +724,14 @@ extern "C" int plsr_rotate_rows(const double *d_U, const double *d_rows_in, doub
   return check_launch();
 }
 
+extern "C" int plsr_svd_finish(const double *d_lam, const double *d_cur, int32_t k, int32_t n, double abs_tol,
+                               double rel_tol, double *d_s, double *d_rows_out, void *stream) {
+  if (!d_lam || !d_cur || !d_s || !d_rows_out || k <= 0 || n <= 0) return PLSR_EINVAL;
+  hipLaunchKernelGGL(svd_finish_kernel, dim3((unsigned)((k * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_lam, d_cur, k, n, abs_tol, rel_tol, d_s, d_rows_out);
+  return check_launch();
+}
+
 // ---------------------------------------------------------------------------
 // K3: gather + per-cell z-score
 // ---------------------------------------------------------------------------

@@ -454,4 +454,23 @@ __global__ void rotate_rows_kernel(const double *U, const double *rows_in, doubl
   rows_out[(int64_t)item * m * n + e] = acc;
 }
 
+// Last step of the thin SVD on the device: singular values from the final pass's eigenvalues,
+// deflation of null latent variables, and the two operators of the back-projection:
+//   rows_out[i]     = live_i ? cur[i]         : 0      ->  (V s)^T = rows_out[:k]  @ X
+//   rows_out[k + i] = live_i ? cur[i] / s_i   : 0      ->   V^T    = rows_out[k:]  @ X
+// with cur = U^T rows (rotate_rows_kernel).  live_i: s_i > max(abs_tol, rel_tol * s_0).
+__global__ void svd_finish_kernel(const double *lam, const double *cur, int k, int n, double abs_tol,
+                                  double rel_tol, double *s_out, double *rows_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= k * n) return;
+  const int i = e / n;
+  const double smax = sqrt(fmax(lam[0], 0.0));
+  const double si = sqrt(fmax(lam[i], 0.0));
+  const bool live = si > fmax(abs_tol, rel_tol * smax);
+  const double x = cur[e];
+  rows_out[e] = live ? x : 0.0;
+  rows_out[(int64_t)k * n + e] = live ? x / si : 0.0;
+  if (e % n == 0) s_out[i] = live ? si : 0.0;
+}
+
 }  // namespace plsr

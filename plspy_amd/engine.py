@@ -51,6 +51,17 @@ class _Lane:
         self.frag = None
 
 
+class _Fetch:
+    """Pending device -> pinned-host copies (ProjectionEngine.fetch_async)."""
+
+    def __init__(self, host, done):
+        self._host, self._done = host, done
+
+    def get(self):
+        self._done.synchronize()
+        return [h.numpy() for h in self._host]
+
+
 class ProjectionEngine:
     """X (n x p, fp64, voxel = unit stride) on one GPU plus scratch.
 
@@ -255,7 +266,7 @@ class ProjectionEngine:
     def apply_operator(self, rows):
         """(m x n) operator rows -> (m x p) = rows @ X on the device (K0; the observed
         cell means / centred block / correlation block / back-projection)."""
-        d_rows = self.dev(np.ascontiguousarray(rows, dtype=np.float64))
+        d_rows = rows.contiguous() if torch.is_tensor(rows) else self.dev(np.ascontiguousarray(rows, dtype=np.float64))
         m, n = d_rows.shape
         if n != self.n:
             raise ValueError(f"operator rows have {n} columns, X has {self.n} rows")
@@ -263,6 +274,19 @@ class ProjectionEngine:
         _lib.check(self.lib.plsr_apply_rows(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_rows), m,
                                             _ptr(out), self.p, _stream()), "plsr_apply_rows")
         return out
+
+    def latents_device(self, vt):
+        """(1, k, n) device tensor (X @ V)^T for V^T = vt (k, p) on the device (K5, one item)."""
+        k = int(vt.shape[0])
+        need = self.lib.plsr_latent_workspace_bytes(self.n, k, 1, self.p)
+        if need == 0:
+            raise _lib.PlsrError(f"plsr_latent: unsupported shape n={self.n} k={k}")
+        vt = vt.contiguous()
+        Zt = torch.empty((1, k, self.n), dtype=torch.float64, device=self.device)
+        work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(vt), self.p, 1, k,
+                                        _ptr(Zt), _ptr(None), _ptr(work), need, _stream()), "plsr_latent")
+        return Zt
 
     def latents(self, V, rows=None):
         """X @ V (n x k) for a host matrix V (p x k): the observed latent scores
@@ -272,16 +296,33 @@ class ProjectionEngine:
         V = np.asarray(V, dtype=np.float64)
         if V.ndim != 2 or V.shape[0] != self.p:
             raise ValueError(f"V must be ({self.p}, k)")
-        k = V.shape[1]
-        need = self.lib.plsr_latent_workspace_bytes(self.n, k, 1, self.p)
-        if need == 0:
-            raise _lib.PlsrError(f"plsr_latent: unsupported shape n={self.n} k={k}")
-        vt = self.dev(V).t().contiguous()                  # (k, p): a layout copy on the device
-        Zt = torch.empty((1, k, self.n), dtype=torch.float64, device=self.device)
-        work = torch.empty(need, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(vt), self.p, 1, k,
-                                        _ptr(Zt), _ptr(None), _ptr(work), need, _stream()), "plsr_latent")
+        Zt = self.latents_device(self.dev(V).t())           # (k, p): a layout copy on the device
         return np.ascontiguousarray(Zt[0].t().cpu().numpy())
+
+    # -- results to the host without stalling the pipeline --------------------------
+    def fetch_async(self, tensors):
+        """Start copying device tensors into page-locked host memory on the download stream
+        (behind everything enqueued on the current stream so far).  Returns a handle whose
+        ``get()`` waits for these copies only and returns NumPy arrays (views of the pinned
+        buffers, which torch's caching host allocator recycles once the arrays are dropped).
+        A `.cpu()` instead would block the host until the whole current stream has drained and
+        move the data through a pageable staging copy."""
+        if self._d2h is None:
+            self._d2h = _side_stream(self.device, "d2h")
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        host = []
+        with torch.cuda.stream(self._d2h):
+            self._d2h.wait_event(ev)
+            for t in tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(self._d2h)
+                host.append(h)
+            done = torch.cuda.Event()
+            done.record(self._d2h)
+        return _Fetch(host, done)
 
     # -- K2: Gram / thin SVD -------------------------------------------------
     def gram_phase(self, rows, gather=None):
@@ -503,9 +544,10 @@ class ProjectionEngine:
 
     SVD_PASSES = 3
 
-    def thin_svd_device(self, rows):
-        """Thin SVD of M = rows @ X (k x p), everything on the device, no host synchronisation:
-        returns (U (k, k), lam (k,) = s^2 descending, VSt (k, p) = (V s)^T) as device tensors.
+    def thin_svd_device(self, rows, null_tol=None):
+        """Thin SVD of M = rows @ X (k x p), everything on the device, no host synchronisation.
+        Returns dict(U (k, k), s (k,) descending with null values deflated to 0, VSt (k, p) =
+        (V s)^T, Vt (k, p) = V^T, UtR (k, n) = U^T rows) of device tensors.
 
         Pass 0: Gram of the rows -> Jacobi.  That alone squares the condition number (a singular
         value 1e-4 of the largest comes out with 1e-8 relative error).  Passes 1..: the rows are
@@ -516,17 +558,20 @@ class ProjectionEngine:
         error); a third is run as a safeguard.  Measured against an 80-bit one-sided Jacobi on
         graded spectra (s_k / s_1 = 1e-7, k = 48): 2e-4 relative after pass 0, 2e-12 after pass 1,
         where LAPACK's dgesdd itself is off by 4e-11."""
-        d_rows = self.dev(np.ascontiguousarray(rows, dtype=np.float64))[None]      # (1, k, n)
-        k = d_rows.shape[1]
+        d_rows = (rows if torch.is_tensor(rows) else self.dev(np.ascontiguousarray(rows, dtype=np.float64)))[None]
+        k, n = int(d_rows.shape[1]), int(d_rows.shape[2])
         cur, U, ev = d_rows, None, None
         for it in range(self.SVD_PASSES):
             G = self.gram_phase(cur)
             ev, U = self.eigh(G, 0, k, init=U, relative=it > 0)
             cur = self.rotate_rows(U, d_rows)              # U^T rows: next pass's rows / back-projection operator
-        VSt = torch.empty((k, self.p), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.plsr_apply_rows(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(cur), k,
-                                            _ptr(VSt), self.p, _stream()), "plsr_apply_rows")
-        return U[0], ev[0], VSt
+        s = torch.empty(k, dtype=torch.float64, device=self.device)
+        ops = torch.empty((2 * k, n), dtype=torch.float64, device=self.device)
+        abs_tol, rel_tol = (1e-12, 4.0 * k * np.finfo(float).eps) if null_tol is None else (0.0, float(null_tol))
+        _lib.check(self.lib.plsr_svd_finish(_ptr(ev), _ptr(cur), k, n, abs_tol, rel_tol, _ptr(s), _ptr(ops),
+                                            _stream()), "plsr_svd_finish")
+        both = self.apply_operator(ops)                    # (2k, p): (V s)^T and V^T in one pass over X
+        return {"U": U[0], "s": s, "VSt": both[:k], "Vt": both[k:], "UtR": cur[0]}
 
     @staticmethod
     def null_threshold(k, smax):
@@ -540,16 +585,6 @@ class ProjectionEngine:
         """Thin SVD of M = rows @ X (k x p) without forming M on the host (class_functions.py:98-123):
         (U, s, V) as NumPy arrays.  Null singular values are deflated to 0 with zero vectors
         (null_threshold; `null_tol` overrides it with a threshold relative to s_max)."""
-        rows = np.asarray(rows, dtype=float)
-        k = rows.shape[0]
-        U, lam, VSt = self.thin_svd_device(rows)
-        packed = torch.cat((U.reshape(-1), lam)).cpu().numpy()     # one small download
-        U, lam = packed[:k * k].reshape(k, k), packed[k * k:]
-        s = np.sqrt(np.maximum(lam, 0.0))
-        tol = self.null_threshold(k, s[0]) if null_tol is None else null_tol * s[0]
-        live = s > tol
-        s = np.where(live, s, 0.0)
-        VS = VSt.cpu().numpy().T                                   # p x k
-        with np.errstate(divide="ignore", invalid="ignore"):
-            V = np.where(live[None, :], VS / s[None, :], 0.0)
-        return U, s, V
+        d = self.thin_svd_device(np.asarray(rows, dtype=float), null_tol)
+        U, s, Vt = self.fetch_async([d["U"], d["s"], d["Vt"]]).get()
+        return U, s, Vt.T

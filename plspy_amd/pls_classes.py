@@ -137,16 +137,34 @@ class _MeanCentreTaskPLS(PLSBase):
         # kernels (engine.thin_svd)
         Wm = operators.cell_mean_operator(co)
         W = operators.mean_centre_operator(co, self.mctype)
-        blocks = engine.apply_operator(np.vstack((Wm, W))).cpu().numpy()
-        self.X_means, self.X_mc = blocks[:len(Wm)], blocks[len(Wm):]
-        self.U, self.s, self.V = engine.thin_svd(W)
-        self.X_latent = engine.latents(self.V)                       # X @ V on the device (K5)
-        Tvsc_orig = Wm @ self.X_latent
+        # Everything below is enqueued without the host waiting for a result: the observed
+        # blocks, the decomposition and the latent scores stay on the device for the resampling
+        # phases (U for the operators, V s as the moment shift, the cell means for Tdistrib) and
+        # travel to the host in page-locked buffers behind the kernels (engine.fetch_async).
+        blocks = engine.apply_operator(np.vstack((Wm, W)))           # (2 cells, p) on the device
+        svd = engine.thin_svd_device(W)
+        Zt = engine.latents_device(svd["Vt"])                        # (X @ V)^T on the device (K5)
+        fetch = engine.fetch_async([blocks, svd["U"], svd["s"], svd["Vt"], Zt])
+        got = {}
+
+        def host():
+            if not got:
+                b, U, sv, Vt, Z = fetch.get()
+                got.update(blocks=b, U=U, s=sv, V=Vt.T, XV=np.ascontiguousarray(Z[0].T))
+            return got["U"], got["s"], got["V"]
+
+        def latent():
+            host()
+            return got["XV"]
+        observed = dict(k=W.shape[0], U=svd["U"], VSt=svd["VSt"], Xm=blocks[:len(Wm)], host=host, XV=latent)
 
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
-            self.pls_alg, self.X, None, self.U, self.s, self.V, self.cond_order, self.mctype,
-            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, Tvsc_orig=Tvsc_orig,
-            CI=self.CI, engine=engine)
+            self.pls_alg, self.X, None, None, None, None, self.cond_order, self.mctype,
+            preprocess=None, nperm=self.num_perm, nboot=self.num_boot, Tvsc_orig=lambda: Wm @ latent(),
+            CI=self.CI, engine=engine, _observed=observed)
+        self.U, self.s, self.V = host()
+        self.X_means, self.X_mc = got["blocks"][:len(Wm)], got["blocks"][len(Wm):]
+        self.X_latent = got["XV"]                                    # X @ V (pls_classes.py:263)
 
         if "num_split" in self._user_defined_attrs:
             self.num_split = int(self.num_split)
