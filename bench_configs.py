@@ -7,6 +7,8 @@
   --config 5   mct X=(240x500000) groups [20]x4 x 3, perm + boot
   --config 2   mct X=(60x200000) through PLS() end to end (host draws, observed SVD included)
   --config 6   mb  config 4's data, permutation + bootstrap (not in BASELINE.json)
+  --config 7   mct X=(128x200000) groups [8]x8 x 2 (k = 16: LDS-fed bootstrap kernel, period 4)
+  --config 8   mct X=(64x200000)  groups [16,16] x 2 (sixteen k-steps: register-resident kernels at nk = 16)
 
 ``--count`` sets the number of resamples per loop (BASELINE's full counts are
 2000/2000, 1000 splits, 5000/5000); rates are per second of the resampling
@@ -64,17 +66,27 @@ def main():
 
     np.random.seed(1234)
     out = {"config": args.config, "device": torch.cuda.get_device_name(0)}
-    if args.config in (2, 5):
-        n, p, groups = (60, 200_000, [10, 10]) if args.config == 2 else (240, 500_000, [20] * 4)
-        R = args.count or (1000 if args.config == 2 else 5000)
+    if args.config in (2, 5, 7, 8):
+        # 7 / 8: mct shapes that used to run spilling instances -- k = 16, n = 128 (LDS-fed bootstrap,
+        # period 4) and n = 64 (the sixteen-step register-resident kernels)
+        nc = 3
+        if args.config == 2:
+            n, p, groups = 60, 200_000, [10, 10]
+        elif args.config == 5:
+            n, p, groups = 240, 500_000, [20] * 4
+        elif args.config == 7:
+            n, p, groups, nc = 128, 200_000, [8] * 8, 2
+        else:
+            n, p, groups, nc = 64, 200_000, [16, 16], 2
+        R = args.count or (5000 if args.config == 5 else 1000)
         X, _ = data(n, p)
-        res, t_all = timed(lambda: plspy_amd.PLS(X, groups, 3, num_perm=R, num_boot=R, pls_method="mct"))
-        out.update(workload=f"mct X={n}x{p}, {R} perm + {R} boot via PLS()", seconds_total=t_all,
+        res, t_all = timed(lambda: plspy_amd.PLS(X, groups, nc, num_perm=R, num_boot=R, pls_method="mct"))
+        out.update(workload=f"mct X={n}x{p}, groups {groups} x {nc}, {R} perm + {R} boot via PLS()", seconds_total=t_all,
                    resamples_per_s_end_to_end=2 * R / t_all, s=res.s.tolist())
         # resampling phases alone (observed decomposition excluded)
         eng = ProjectionEngine(X)
         U, s, V = res.V, res.s.copy(), res.U
-        co = np.array([[g] * 3 for g in groups])
+        co = np.array([[g] * nc for g in groups])
         rt, t_rs = timed(lambda: ResampleTest._create("mct", X, None, U, s.copy(), V, co, 0, nperm=R, nboot=R,
                                                       Tvsc_orig=np.zeros((len(s), len(s))), engine=eng), "resampling")
         out.update(seconds_resampling=t_rs, resamples_per_s=2 * R / t_rs)

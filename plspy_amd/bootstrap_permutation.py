@@ -94,7 +94,7 @@ class _ResampleTestPLS(ResampleTest):
     def __init__(self, X, Y, U, s, V, cond_order, mctype, contrast=None, preprocess=None,
                  nperm=1000, nboot=1000, bscan=None, Xbscan=None, Ybscan=None,
                  lvcorrs_orig=None, Tvsc_orig=None, CI=0.95, engine=None, keep_right_sv=False,
-                 _pls_alg=None, _observed=None):
+                 _pls_alg=None, _observed=None, _predrawn=None):
         self.pls_alg = _pls_alg or self.pls_alg
         # _observed (private, from the PLS classes): the observed decomposition as it sits on the
         # device -- dict(k, U (k, k), VSt (k, p) = (V s)^T, Xm (cells, p) cell means, host() ->
@@ -102,6 +102,9 @@ class _ResampleTestPLS(ResampleTest):
         # With it the phases are enqueued without waiting for U / s / V on the host; the host
         # arrays U, s, V may then be None.
         self._obs = _observed
+        # _predrawn (private): (permutation, bootstrap) index tables already drawn by the caller in
+        # the reference's order (while X was being uploaded)
+        self._predrawn = _predrawn
         self.CI = CI
         self._cond_order = np.asarray(cond_order)
         self._mctype = mctype
@@ -228,7 +231,10 @@ class _ResampleTestPLS(ResampleTest):
             k = Uq.shape[1]
             s[np.abs(s) < threshold] = 0        # in place, like the reference (:295, quirk Q1)
             M = self._W.T @ Uq                  # n x k:  VS = X^T (P^T W^T U)
-        inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
+        if self._predrawn is not None and self._predrawn[0] is not None:
+            inds = self._predrawn[0]
+        else:
+            inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
         pending = []
 
         def launch():
@@ -393,7 +399,10 @@ class _ResampleTestPLS(ResampleTest):
         co = self._cond_order
         obs = self._obs if self._C is None else None
         rank, nranks = dist.world()
-        inds = self._draw_on_rank0(lambda: resample.bootstraps(co, niter))
+        if self._predrawn is not None and self._predrawn[1] is not None:
+            inds = self._predrawn[1]
+        else:
+            inds = self._draw_on_rank0(lambda: resample.bootstraps(co, niter))
         lo, hi = dist.shard_bounds(niter, rank, nranks)
         Wm = operators.cell_mean_operator(co)
         if obs is not None:

@@ -295,7 +295,7 @@ ProjectKernel boot_instance(int nh) {
 
 template <int MODE>
 int launch_project(const ProjectArgs &a, int period, int64_t nvt, int nsplit, hipStream_t st) {
-  const int nw = lds_fed_waves(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp);
+  const int nw = lds_fed_waves(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp, MODE);
   size_t lds = project_lds_bytes(a.nk, period, MODE != 0, (a.k2 + 3) / 4, a.kp, nw);
 #if PLSR_ABLATE & 256
   if (MODE == 0) lds += 40 * 1024;   // dev: force the permutation kernel down to two workgroups per CU
@@ -613,7 +613,9 @@ bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, bool per_item_x, 
   {
     const size_t ops = (size_t)g.B * g.MC * nk * 512;
     const int fit = (int)((160 * 1024 - ops) / 2048);
-    g.ks = std::min(std::min(nk, fit), GRAM_PF);      // a thread parks ks rows of the next chunk in registers
+    // a thread parks ks rows of the next chunk in registers (gram_pf: fewer for the six-tile
+    // items with their own data, whose 21 Gram tiles leave less room)
+    g.ks = std::min(std::min(nk, fit), gram_pf(g.MC, per_item_x));
     if (g.ks < 1) return false;
   }
   g.lds = gram_lds_bytes(nk, g.MC, g.B, g.ks);

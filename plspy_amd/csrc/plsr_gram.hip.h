@@ -45,6 +45,10 @@ struct GramArgs {
 };
 
 constexpr int GRAM_PF = 20;   // rows of X a thread parks in registers per K-chunk (ks <= GRAM_PF)
+// ... except for six-tile items that stage their own gathered / z-scored rows (m = 81..96, e.g.
+// behaviour split-half with k = 48): 21 Gram tiles + three parked values per row spilled
+// 124 bytes per lane at 20 rows (16 at 10); 8 rows fit
+constexpr int gram_pf(int mc, bool own_rows) { return (own_rows && mc >= 6) ? 8 : GRAM_PF; }
 
 // MC = 16-row tiles per item, B = items per workgroup
 template <int MC, int B, bool FUSED = false>
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
     }
     return q;
   };
-  double px[GRAM_PF], psc[FUSED ? GRAM_PF : 1], psh[FUSED ? GRAM_PF : 1];
+  constexpr int PF = gram_pf(MC, FUSED);
+  double px[PF], psc[FUSED ? PF : 1], psh[FUSED ? PF : 1];
   // FUSED: the item's source-row and cell tables (n <= 256 entries each) live in four
   // vector registers apiece, entry r in lane r & 63 of register r >> 6; a row's entry
   // comes out through v_readlane.  Read from memory per row they were dependent loads
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       const int rbeg = 4 * q.ks0 + wave * rpw;
       const int rend = min(4 * ks1, rbeg + rpw);
 #pragma unroll
-      for (int u = 0; u < GRAM_PF; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const int row = rbeg + u;
         const bool ok = row < rend && row < A.n;
         const int rc = ok ? row : 0;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < GRAM_PF; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const int row = 4 * q.ks0 + 4 * u + wave;
         const bool ok = row < 4 * ks1 && row < A.n;
         const double x = Xi[(int64_t)(ok ? row : 0) * A.ldx + vc];
@@ -170,13 +175,13 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       const int rbeg = 4 * q.ks0 + wave * rpw;
       const int rend = min(4 * ks1, rbeg + rpw);
 #pragma unroll
-      for (int u = 0; u < GRAM_PF; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const int row = rbeg + u;
         if (row < rend) Xs[xs_index(row - 4 * q.ks0, lane)] = fma(px[u], psc[FUSED ? u : 0], psh[FUSED ? u : 0]);
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < GRAM_PF; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const int row = 4 * q.ks0 + 4 * u + wave;
         if (row < 4 * ks1) Xs[xs_index(row - 4 * q.ks0, lane)] = px[u];
       }

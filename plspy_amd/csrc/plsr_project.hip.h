@@ -78,8 +78,20 @@ __device__ __forceinline__ int xs_index(int row, int v) {
 // NHT: halves (groups of four cells) of the second matrix, compile-time for the
 // hot bootstrap instance (a run-time count in the unrolled MFMA loop costs ~15 %);
 // -1 = take it from the arguments (dump mode), 0 = no second matrix.
+// Largest workgroup an instance may be launched with (lds_fed_waves respects it).  The bootstrap
+// instances keep 2 * PERIOD * NT moment accumulators in registers: with PERIOD >= 4 (and in dump
+// mode) they need more than the 168 VGPRs a twelve-wave workgroup leaves a wave, and used to
+// spill 32-250 bytes per lane; eight waves (256 VGPRs) hold them.
+template <int PERIOD, int MODE>
+constexpr int project_max_threads() {
+  return MODE == 0 ? 1024 : ((MODE == 1 && PERIOD <= 3) ? 768 : 512);
+}
+inline int project_max_waves(int period, int mode) {
+  return mode == 0 ? 16 : ((mode == 1 && period <= 3) ? 12 : 8);
+}
+
 template <int PERIOD, int MODE, int NHT>
-__global__ __launch_bounds__(MODE == 0 ? 1024 : 768, (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
+__global__ __launch_bounds__((project_max_threads<PERIOD, MODE>()), (MODE == 1 && PERIOD <= 3) ? 3 : 2) void project_kernel(ProjectArgs A) {
   constexpr bool BOOT = MODE != 0;
   constexpr bool DUMP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -507,8 +519,12 @@ __global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) 
 // NHT: number of four-cell groups of the second matrix at compile time (-1: from the
 // arguments); with it the tile loop has no branch at all, which is what lets the
 // compiler keep the fragment loads in flight across the loop's back-edge.
+// (occupancy: two waves per SIMD up to NK = 15 -- 252 VGPRs at NK = 15; the sixteen-step instance
+// (n = 61..64) and the dump instances from NK = 12 on do not fit 256 and spilled 12-164 bytes per
+// lane: they take one wave per SIMD, where a register-fed fp64 MFMA loop still runs at 74 of
+// the 77 TFLOP/s, microbench/mfma_f64_regB.hip)
 template <int NK, bool DUMP, int NHT>
-__global__ __launch_bounds__(64, 2) void project_boot_reg_kernel(ProjectArgs A) {
+__global__ __launch_bounds__(64, (NK >= 16 || (DUMP && NK >= 12)) ? 1 : 2) void project_boot_reg_kernel(ProjectArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int col = lane & 15;
@@ -739,7 +755,9 @@ inline size_t project_lds_bytes(int nk, int period, bool boot, int nh, int kp, i
 // more than half of the CU's 160 KB only one workgroup is resident, and four waves would
 // leave each SIMD with a single wave (LDS-fed fp64 MFMA: 58 TFLOP/s at one wave per SIMD,
 // 66 at two, microbench/mfma_f64_data) -- eight waves then, if the per-wave patches still fit.
-inline int lds_fed_waves(int nk, int period, bool boot, int nh, int kp) {
+inline int lds_fed_waves(int nk, int period, bool boot, int nh, int kp, int mode = -1) {
+  if (mode < 0) mode = boot ? 1 : 0;
+  const int cap = project_max_waves(period, mode);
   const size_t tile = (size_t)nk * 4 * TV * sizeof(double);
   // (the permutation instance needs 94 VGPRs only: from two workgroups per CU on -- X tile above
   // 36 KB, n > 72 -- eight waves each put four waves on a SIMD: -2.5 % at n = 120)
@@ -748,7 +766,7 @@ inline int lds_fed_waves(int nk, int period, bool boot, int nh, int kp) {
     // one workgroup per CU: as many waves as the registers (bootstrap 165 VGPRs: three per
     // SIMD; permutation: four) and the per-wave patches in LDS allow -- config 5 (n = 240):
     // ten / fourteen waves, another 2 % over eight
-    for (int nw = boot ? 12 : 16; nw > 2 * WAVES; nw -= 2)
+    for (int nw = cap; nw > 2 * WAVES; nw -= 2)
       if (project_lds_bytes(nk, period, boot, nh, kp, nw) <= 160 * 1024) return nw;
   }
   return project_lds_bytes(nk, period, boot, nh, kp, 2 * WAVES) <= 160 * 1024 ? 2 * WAVES : WAVES;

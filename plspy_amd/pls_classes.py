@@ -129,8 +129,36 @@ class _MeanCentreTaskPLS(PLSBase):
         else:
             self.mctype = mctype
 
-        engine = ProjectionEngine(X)
         co = np.asarray(self.cond_order)
+        # The upload of X (a blocking copy out of pageable memory, 2 ms at 60 x 200 000) runs in a
+        # helper thread while this one draws the resampling indices (native generator on
+        # np.random's state; permutation draws before bootstrap draws, as the reference's loops
+        # consume them -- the observed decomposition itself draws nothing).
+        import threading
+        import torch
+        from . import dist, resample
+        box = {}
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def upload():
+            try:
+                if dev is not None:
+                    torch.cuda.set_device(dev)
+                box["engine"] = ProjectionEngine(X, device=None if dev is None else f"cuda:{dev}")
+            except BaseException as e:                       # re-raised in the caller's thread
+                box["error"] = e
+        th = threading.Thread(target=upload)
+        th.start()
+        predrawn = None
+        try:
+            if dist.world()[1] == 1:
+                predrawn = (resample.task_permutations(co, num_perm) if num_perm > 0 else None,
+                            resample.bootstraps(co, num_boot) if num_boot > 0 else None)
+        finally:
+            th.join()
+        if "error" in box:
+            raise box["error"]
+        engine = box["engine"]
         # observed decomposition (pls_classes.py:258-266), on the device: the
         # two k x p blocks come from the projection kernel, the thin SVD
         # (class_functions.py:122) from the Gram + Jacobi + back-projection
@@ -161,7 +189,7 @@ class _MeanCentreTaskPLS(PLSBase):
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
             self.pls_alg, self.X, None, None, None, None, self.cond_order, self.mctype,
             preprocess=None, nperm=self.num_perm, nboot=self.num_boot, Tvsc_orig=lambda: Wm @ latent(),
-            CI=self.CI, engine=engine, _observed=observed)
+            CI=self.CI, engine=engine, _observed=observed, _predrawn=predrawn)
         self.U, self.s, self.V = host()
         self.X_means, self.X_mc = got["blocks"][:len(Wm)], got["blocks"][len(Wm):]
         self.X_latent = got["XV"]                                    # X @ V (pls_classes.py:263)
