@@ -282,6 +282,39 @@ int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     double *d_sh, int32_t stats_ready, void *d_work, size_t work_bytes, void *stream);
 
 /*
+ * ---- K4a: the same product on aggregated operators, X in registers -------------
+ * plsr_item_fused for items whose cells draw their rows from FIXED RANGES of source rows --
+ * what the reference's bootstrap does (resample.py:132-160: subjects within their group, the
+ * same draw for every condition; bootstrap_permutation.py:547-557), so cell c of every item
+ * reads rows src_lo[c] <= r < src_hi[c] of X only.  The gather then folds into the operator
+ * (A_bc[j][r] = sum of rows_b[j][i] over the cell's rows i with d_src[b][i] == r), every
+ * k-step of every item reads the same rows of X, and a wave keeps X[:, 16 voxels] in
+ * registers for all items; the per-(item, cell, voxel) statistics of four items at a time
+ * come from v_mfma_f64_4x4x4 on the same registers (no statistics kernel, nothing through HBM).
+ * Replaces class_functions.py:185-247 + :454-516 on X[inds] and the projection
+ * bootstrap_permutation.py:620 inside the bootstrap loop (:537-675) for rb / mb / csb / cmb.
+ *   src_lo / src_hi : HOST [ncell] source-row range of every cell.  An item that reads a row
+ *             outside its cell's range comes out as NaN (all its outputs and the moment sums).
+ *   other arguments and outputs as plsr_item_fused (no caller-held statistics).
+ * Differences in arithmetic from plsr_item_fused: the variance is formed in one pass on data
+ * centred by the per-voxel grand mean; a cell whose sample variance is below 16 eps of its
+ * second moment about that mean is treated as constant (z = 0), next to the reference's
+ * sd <= eps |mean| rule.
+ * plsr_item_agg_workspace_bytes returns 0 when the shape is not served (n > 128, k > 48,
+ * more than 16 z-scored cells, or cells whose ranges overlap so much that the dense sweeps
+ * would cost over 4/3 of plsr_item_fused's k-steps): call plsr_item_fused then.
+ */
+size_t plsr_item_agg_workspace_bytes(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo,
+                                     const int32_t *cell_z, const int32_t *src_lo, const int32_t *src_hi,
+                                     int32_t ncell, int32_t items, int64_t p, int32_t want_moments,
+                                     int32_t want_rowsq);
+int plsr_item_agg(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src, int32_t nz,
+                  const int32_t *cell_lo, const int32_t *cell_z, const int32_t *src_lo,
+                  const int32_t *src_hi, int32_t ncell, const double *d_rows, int32_t items, int32_t k,
+                  const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv,
+                  double *d_rowsq, void *d_work, size_t work_bytes, void *stream);
+
+/*
  * Multiblock operator rows for plsr_item_fused, formed on the device from the
  * un-normalised rows and the squared row norms plsr_item_fused returned for them
  * (two-phase row normalisation, class_functions.py:503-505, then `@ U`, :620):

@@ -49,6 +49,10 @@ SIGNATURES = {
     "plsr_item_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32]),
     "plsr_item_fused": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32,
                                 c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "plsr_item_agg_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32,
+                                             c_i32]),
+    "plsr_item_agg": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
+                              c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "plsr_gram_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64]),
     "plsr_gram_fused": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32,
                                 c_vp, c_vp, c_sz, c_vp]),

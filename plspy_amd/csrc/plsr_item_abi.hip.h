@@ -4,9 +4,13 @@
 #include "../../include/plsr.h"
 #include "plsr_item.hip.h"
 #include "plsr_fused.hip.h"
+#include "plsr_agg.hip.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
 
 using namespace plsr;
 
@@ -313,7 +317,6 @@ extern "C" int plsr_item_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   a.rowoff = ma.rowoff;
   a.sc = sa.sc;
   a.sh = sa.sh;
-  a.ref = d_ref;
   a.S1 = d_S1 ? (double *)(w + pl.o_mom) : nullptr;
   a.S2 = d_S1 ? a.S1 + (size_t)pl.nslabm * p * k : nullptr;
   a.flat = pl.flat;
@@ -477,5 +480,274 @@ extern "C" int plsr_scale_project_rows(const double *d_raw, const double *d_rows
   const int64_t total = (int64_t)items * k * nz;
   hipLaunchKernelGGL(scale_project_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, d_raw, d_rowsq, rowsq_stride, d_U, items, kr, nz, k, d_out);
+  return launch_ok();
+}
+
+// ---------------------------------------------------------------------------
+// K4a: the same product on aggregated operators, X in registers (plsr_agg.hip.h)
+// ---------------------------------------------------------------------------
+namespace {
+struct AggPlan {
+  AggProgram prog;
+  int MC, NF, nsplit, per, ngroups, unit, nups, us;
+  int64_t nwg, ntile;
+  int nchunk;
+  size_t lds;
+  size_t o_prog, o_afrag, o_mfrag, o_mom, o_sq, o_sq2, bytes;
+};
+
+// fragment counts item_agg_kernel is instantiated for
+int agg_nf_instance(int nf) {
+  static const int inst[] = {8, 16, 24, 30, 32};
+  for (int v : inst)
+    if (nf <= v) return v;
+  return 0;
+}
+
+bool agg_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const int32_t *cell_z,
+              const int32_t *src_lo, const int32_t *src_hi, int32_t ncell, int32_t items, int64_t p,
+              bool moments, bool rowsq, AggPlan &pl) {
+  if (n <= 0 || n > AG_MAXROWS || nz <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
+  if (!cell_lo || !cell_z || !src_lo || !src_hi || ncell <= 0 || ncell > FZ_MAXCELL) return false;
+  if (cell_lo[0] != 0 || cell_lo[ncell] != nz) return false;
+  pl.MC = (k + 15) / 16;
+  if (pl.MC > 3) return false;
+  pl.NF = agg_nf_instance((n + 3) / 4);
+  if (!pl.NF) return false;
+  AggProgram &g = pl.prog;
+  memset(&g, 0, sizeof(g));
+  memset(g.rowcell, 0xff, sizeof(g.rowcell));
+  // cells to sweeps: ascending first fragment, each into the first sweep whose cells end before it
+  int order[FZ_MAXCELL], last[AG_MAXSWEEP], sweep_of[FZ_MAXCELL];
+  int old_steps = 0;
+  for (int c = 0; c < ncell; ++c) {
+    if (cell_lo[c + 1] <= cell_lo[c] || src_lo[c] < 0 || src_hi[c] > n || src_hi[c] <= src_lo[c]) return false;
+    order[c] = c;
+    old_steps += (cell_lo[c + 1] - cell_lo[c] + 3) / 4;
+  }
+  std::stable_sort(order, order + ncell, [&](int a, int b) { return src_lo[a] < src_lo[b]; });
+  g.nsweep = 0;
+  for (int q = 0; q < ncell; ++q) {
+    const int c = order[q];
+    const int f0 = src_lo[c] / 4, f1 = (src_hi[c] - 1) / 4;
+    int sw = 0;
+    while (sw < g.nsweep && last[sw] >= f0) ++sw;
+    if (sw == g.nsweep) {
+      if (g.nsweep == AG_MAXSWEEP) return false;
+      ++g.nsweep;
+    }
+    last[sw] = f1;
+    sweep_of[c] = sw;
+    g.start[sw] |= 1u << f0;
+    if (cell_z[c]) g.zstart[sw] |= 1u << f0;
+    for (int r = src_lo[c]; r < src_hi[c]; ++r) g.rowcell[sw][r] = (int8_t)c;
+  }
+  // dense sweeps: every sweep walks all NF fragments -- not worth it when the cells leave most
+  // of them empty (arbitrary gathers: every cell may read every row)
+  if ((int64_t)g.nsweep * pl.NF * 3 > (int64_t)old_steps * 4 + 3 * 8) return false;
+  // z-scored cells in the order the kernel meets them: sweep by sweep, ascending fragment
+  g.nzsweep = 0;
+  g.nzc = 0;
+  for (int sw = 0; sw < g.nsweep; ++sw) {
+    if (!g.zstart[sw]) continue;
+    const int zs = g.nzsweep++;
+    g.zsweep[zs] = sw;
+    for (int q = 0; q < ncell; ++q) {
+      const int c = order[q];
+      if (sweep_of[c] != sw || !cell_z[c]) continue;
+      if (g.nzc == AG_MAXZC) return false;
+      g.zend[zs] |= 1u << ((src_hi[c] - 1) / 4);
+      g.zc_zs[g.nzc] = (int8_t)zs;
+      g.zc_flo[g.nzc] = (int8_t)(src_lo[c] / 4);
+      g.zc_fhi[g.nzc] = (int8_t)((src_hi[c] - 1) / 4);
+      g.cnt[g.nzc] = (double)(cell_lo[c + 1] - cell_lo[c]);
+      g.rcnt[g.nzc] = 1.0 / g.cnt[g.nzc];
+      ++g.nzc;
+    }
+  }
+  pl.ngroups = (items + 3) / 4;
+  pl.nwg = (p + 16 * AG_WAVES - 1) / (16 * AG_WAVES);
+  pl.ntile = pl.nwg * AG_WAVES;
+  // splits of the items: fill the 512 workgroup slots of the chip (two per CU) evenly; every
+  // split costs a slab of partial moment sums, so take the first that wastes < 6 % of the last round
+  pl.nsplit = 1;
+  {
+    double best = 0.0;
+    for (int ns = 1; ns <= std::min(8, pl.ngroups); ++ns) {
+      const double rounds = (double)pl.nwg * ns / 512.0;
+      const double eff = rounds / std::ceil(rounds);
+      if (eff > best + 1e-9) {
+        best = eff;
+        pl.nsplit = ns;
+      }
+      if (eff >= 0.94) break;
+    }
+  }
+  pl.per = (pl.ngroups + pl.nsplit - 1) / pl.nsplit * 4;
+  pl.nsplit = (items + pl.per - 1) / pl.per;
+  pl.unit = agg_unit_elems(pl.NF, pl.MC);
+  pl.nups = agg_units_per_sweep(pl.NF, pl.MC);
+  pl.us = agg_unit_steps(pl.NF, pl.MC);
+  pl.lds = ((size_t)2 * pl.unit + (size_t)AG_WAVES * g.nzc * 128 + 2 * AG_MAXZC) * sizeof(double);   // two units, scale / shift, counts
+  if (pl.lds > 160 * 1024) return false;
+  pl.nchunk = (int)((pl.ntile + 63) / 64);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t E = (size_t)items * pl.MC * 16;
+  pl.o_prog = take(sizeof(AggProgram));
+  pl.o_afrag = take(((size_t)items * g.nsweep * pl.nups + 1) * pl.unit * sizeof(double));   // + the unit the staging reads ahead
+  pl.o_mfrag = take(((size_t)pl.ngroups * g.nzsweep * pl.NF + AG_SRING) * 64 * sizeof(double));
+  pl.o_mom = take(moments ? (size_t)2 * pl.nsplit * p * k * sizeof(double) : 0);
+  pl.o_sq = take(rowsq ? (size_t)pl.ntile * E * sizeof(double) : 0);
+  pl.o_sq2 = take(rowsq ? (size_t)pl.nchunk * E * sizeof(double) : 0);
+  pl.bytes = off;
+  return true;
+}
+
+template <int NF, int MC>
+int run_agg(const AggArgs &a, const AggPlan &pl, hipStream_t st) {
+  auto kern = item_agg_kernel<NF, MC>;
+  if (pl.lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+    return PLSR_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)pl.nwg, (unsigned)pl.nsplit), dim3(AG_WAVES * 64), pl.lds, st, a);
+  return launch_ok();
+}
+
+template <int NF>
+int run_agg_mc(const AggArgs &a, const AggPlan &pl, hipStream_t st) {
+  switch (pl.MC) {
+    case 1: return run_agg<NF, 1>(a, pl, st);
+    case 2: return run_agg<NF, 2>(a, pl, st);
+    case 3: return run_agg<NF, 3>(a, pl, st);
+  }
+  return PLSR_EUNSUPPORTED;
+}
+}  // namespace
+
+extern "C" size_t plsr_item_agg_workspace_bytes(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo,
+                                                const int32_t *cell_z, const int32_t *src_lo,
+                                                const int32_t *src_hi, int32_t ncell, int32_t items, int64_t p,
+                                                int32_t want_moments, int32_t want_rowsq) {
+  AggPlan pl;
+  return agg_plan(n, nz, k, cell_lo, cell_z, src_lo, src_hi, ncell, items, p, want_moments != 0, want_rowsq != 0,
+                  pl)
+             ? pl.bytes
+             : 0;
+}
+
+extern "C" int plsr_item_agg(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src, int32_t nz,
+                             const int32_t *cell_lo, const int32_t *cell_z, const int32_t *src_lo,
+                             const int32_t *src_hi, int32_t ncell, const double *d_rows, int32_t items, int32_t k,
+                             const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv,
+                             double *d_rowsq, void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_src || !d_rows || !d_work || !cell_lo || !cell_z || !src_lo || !src_hi || ldx < p)
+    return PLSR_EINVAL;
+  if ((d_S1 == nullptr) != (d_S2 == nullptr) || (d_vst && ldv < p)) return PLSR_EINVAL;
+  if (d_vst && (12 * ldv + p) * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;   // 32-bit lane offsets of the stores
+  AggPlan pl;
+  if (!agg_plan(n, nz, k, cell_lo, cell_z, src_lo, src_hi, ncell, items, p, d_S1 != nullptr, d_rowsq != nullptr, pl))
+    return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char *w = (char *)d_work;
+
+  AggMetaArgs ma;
+  ma.rows = d_rows;
+  ma.src = d_src;
+  ma.items = items;
+  ma.k = k;
+  ma.nz = nz;
+  ma.MC = pl.MC;
+  ma.NF = pl.NF;
+  ma.ncell = ncell;
+  for (int c = 0; c < ncell; ++c) {
+    ma.cell_lo[c] = cell_lo[c];
+    ma.src_lo[c] = src_lo[c];
+    ma.src_hi[c] = src_hi[c];
+    ma.cell_z[c] = cell_z[c];
+  }
+  ma.cell_lo[ncell] = cell_lo[ncell];
+  ma.prog = pl.prog;
+  ma.afrag = (double *)(w + pl.o_afrag);
+  ma.mfrag = (double *)(w + pl.o_mfrag);
+  ma.prog_out = (AggProgram *)(w + pl.o_prog);
+  ma.unit = pl.unit;
+  ma.nups = pl.nups;
+  ma.us = pl.us;
+  const int64_t na = (int64_t)items * pl.prog.nsweep * pl.nups * pl.unit;
+  const int64_t nm = (int64_t)pl.ngroups * pl.prog.nzsweep * pl.NF * 64;
+  // the multiplicity ring runs AG_SRING k-steps past the end: keep that padding defined
+  (void)hipMemsetAsync(ma.mfrag + nm, 0, (size_t)AG_SRING * 64 * sizeof(double), st);
+  hipLaunchKernelGGL(agg_meta_kernel, dim3((unsigned)((na + nm + 255) / 256)), dim3(256), 0, st, ma);
+  hipLaunchKernelGGL(agg_check_kernel, dim3((unsigned)(((int64_t)items * nz + 255) / 256)), dim3(256), 0, st, ma);
+
+  AggArgs a;
+  a.X = d_X;
+  a.ldx = ldx;
+  a.p = p;
+  a.n = n;
+  a.items = items;
+  a.k = k;
+  a.per = pl.per;
+  a.prog = ma.prog_out;
+  a.afrag = ma.afrag;
+  a.mfrag = ma.mfrag;
+  a.S1 = d_S1 ? (double *)(w + pl.o_mom) : nullptr;
+  a.S2 = d_S1 ? a.S1 + (size_t)pl.nsplit * p * k : nullptr;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  a.rowsq_part = d_rowsq ? (double *)(w + pl.o_sq) : nullptr;
+#ifdef AGG_TIMING
+  static long long *dbg = nullptr;
+  const size_t ndbg = (size_t)pl.nwg * pl.nsplit * AG_WAVES * 8;
+  if (!dbg) (void)hipMalloc(&dbg, 64 << 20);
+  (void)hipMemsetAsync(dbg, 0, ndbg * 8, st);
+  a.dbg = dbg;
+#endif
+  int rc = PLSR_EUNSUPPORTED;
+  switch (pl.NF) {
+    case 8: rc = run_agg_mc<8>(a, pl, st); break;
+    case 16: rc = run_agg_mc<16>(a, pl, st); break;
+    case 24: rc = run_agg_mc<24>(a, pl, st); break;
+    case 30: rc = run_agg_mc<30>(a, pl, st); break;
+    case 32: rc = run_agg_mc<32>(a, pl, st); break;
+  }
+  if (rc) return rc;
+#ifdef AGG_TIMING
+  {
+    std::vector<long long> h(ndbg);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), dbg, ndbg * 8, hipMemcpyDeviceToHost);
+    double sum[5] = {0, 0, 0, 0, 0};
+    long long tmin = -1, tmax = 0, n_it = 0;
+    for (size_t i = 0; i < ndbg / 8; ++i) {
+      for (int q = 0; q < 5; ++q) sum[q] += (double)h[i * 8 + q];
+      n_it += h[i * 8 + 5];
+      if (tmin < 0 || h[i * 8 + 6] < tmin) tmin = h[i * 8 + 6];
+      tmax = std::max(tmax, h[i * 8 + 6] + h[i * 8]);
+    }
+    fprintf(stderr, "[agg timing] waves %zu, clock ticks per wave-item: total %.0f stats %.0f loop %.0f (barrier %.0f) "
+            "epilogue %.0f; kernel span %lld ticks\n", ndbg / 8, sum[0] / n_it, sum[1] / n_it, sum[2] / n_it,
+            sum[3] / n_it, sum[4] / n_it, tmax - tmin);
+  }
+#endif
+  if (d_S1) {
+    const int64_t cnt = p * k;
+    hipLaunchKernelGGL(moment_unshift_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_S1, d_S2,
+                       (const double *)a.S1, (const double *)a.S2, d_ref, cnt, pl.nsplit, (double)items);
+  }
+  if (d_rowsq) {
+    const int64_t E = (int64_t)items * pl.MC * 16;
+    double *lvl2 = (double *)(w + pl.o_sq2);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)pl.nchunk), dim3(256), 0, st,
+                       (const double *)a.rowsq_part, lvl2, E, (int)pl.ntile, 64);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
+                       (const double *)lvl2, d_rowsq, E, pl.nchunk, pl.nchunk);
+  }
   return launch_ok();
 }

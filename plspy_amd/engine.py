@@ -395,13 +395,37 @@ class ProjectionEngine:
         return out
 
     # -- K4 / K5: bootstrap with per-resample matrices --------------------------
+    @staticmethod
+    def source_ranges(src, cell_lo):
+        """(src_lo, src_hi): per cell, the range of source rows the items of `src` (items, nz;
+        NumPy) read -- what plsr_item_agg needs to know (a bootstrap draws a cell's rows from
+        the cell's own subjects, resample.py:132-160)."""
+        src = np.asarray(src)
+        lo = np.array([src[:, a:b].min() for a, b in zip(cell_lo[:-1], cell_lo[1:])], dtype=np.int32)
+        hi = np.array([src[:, a:b].max() + 1 for a, b in zip(cell_lo[:-1], cell_lo[1:])], dtype=np.int32)
+        return lo, hi
+
+    def _agg_bytes(self, nz, k, cell_lo, cell_z, ranges, items, moments, rowsq):
+        """Workspace of plsr_item_agg for this shape, 0 when it does not serve it."""
+        ncell = len(cell_z)
+        lo = (ctypes.c_int32 * (ncell + 1))(*[int(x) for x in cell_lo])
+        zf = (ctypes.c_int32 * ncell)(*[int(x) for x in cell_z])
+        slo = (ctypes.c_int32 * ncell)(*[int(x) for x in ranges[0]])
+        shi = (ctypes.c_int32 * ncell)(*[int(x) for x in ranges[1]])
+        return self.lib.plsr_item_agg_workspace_bytes(self.n, nz, k, lo, zf, slo, shi, ncell, items, self.p,
+                                                      int(moments), int(rowsq))
+
     def item_fused(self, src, cell_lo, cell_z, rows, ref=None, S1=None, S2=None, want_vst=False,
-                   want_rowsq=False, stats=None):
-        """K4f: VS_b = rows_b @ Z_b for every item without materialising Z_b
+                   want_rowsq=False, stats=None, src_ranges=None):
+        """K4a / K4f: VS_b = rows_b @ Z_b for every item without materialising Z_b
         (Z_b = X[src_b] z-scored within the cells flagged in cell_z).
         rows (items, k, nz).  S1 / S2 (p, k) are accumulated into when given.
-        stats: None, or a dict shared by several calls on the SAME src / cells: the first call
-        stores the per-(item, cell, voxel) scale and shift in it, later calls reuse them.
+        src_ranges: None, or (src_lo, src_hi) -- the source-row range of every cell
+        (source_ranges); the aggregated-operator kernel (plsr_item_agg) then serves when the
+        shape allows, the gathering kernel (plsr_item_fused) otherwise.
+        stats: None, or a dict shared by several calls of the gathering kernel on the SAME src /
+        cells: the first call stores the per-(item, cell, voxel) scale and shift in it, later
+        calls reuse them.
         Returns (vst (items, k, p) or None, rowsq (items, k) or None)."""
         d_src = self.dev(src, torch.int32)
         d_rows = self.dev(rows)
@@ -410,6 +434,24 @@ class ProjectionEngine:
         lo = (ctypes.c_int32 * (len(cell_lo)))(*[int(x) for x in cell_lo])
         zf = (ctypes.c_int32 * (len(cell_z)))(*[int(x) for x in cell_z])
         ncell = len(cell_z)
+        if src_ranges is not None:
+            slo = (ctypes.c_int32 * ncell)(*[int(x) for x in src_ranges[0]])
+            shi = (ctypes.c_int32 * ncell)(*[int(x) for x in src_ranges[1]])
+            need = self.lib.plsr_item_agg_workspace_bytes(self.n, nz, k, lo, zf, slo, shi, ncell, items, self.p,
+                                                          int(S1 is not None), int(want_rowsq))
+            if need:
+                self.last_item_kernel = "agg"
+                work = torch.empty(need, dtype=torch.uint8, device=self.device)
+                refd = self.dev(ref)
+                vst = torch.empty((items, k, self.p), dtype=torch.float64, device=self.device) if want_vst else None
+                k16 = (k + 15) // 16 * 16
+                rowsq = torch.empty((items, k16), dtype=torch.float64, device=self.device) if want_rowsq else None
+                _lib.check(self.lib.plsr_item_agg(
+                    _ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_src), nz, lo, zf, slo, shi, ncell,
+                    _ptr(d_rows), items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p, _ptr(rowsq),
+                    _ptr(work), need, _stream()), "plsr_item_agg")
+                return vst, (rowsq[:, :k] if want_rowsq else None)
+        self.last_item_kernel = "gather"
         need = self.lib.plsr_item_fused_workspace_bytes(self.n, nz, k, lo, ncell, items, self.p,
                                                         int(S1 is not None), int(want_rowsq))
         if need == 0:
@@ -477,18 +519,23 @@ class ProjectionEngine:
                 nsq_h = nsq[blo:bhi].to("cpu")
             on_batch(blo, bhi, zt_h.numpy(), nsq_h.numpy())
 
+        # the cells of a bootstrap sample read fixed ranges of source rows: aggregated-operator
+        # kernel (K4a) when the shape allows; it leaves the column norms to the latent kernel
+        ranges = self.source_ranges(src, cell_lo)
         for lo in range(0, R, step):
             hi = min(R, lo + step)
             cnt = hi - lo
             d_src = self.dev(src[lo:hi], torch.int32)
+            use_agg = self._agg_bytes(nz, k, cell_lo, cell_z, ranges, cnt, True, False) > 0
             rownorm = None
             if raw_rows_fn is not None:
                 # two-phase row normalisation of the multiblock (class_functions.py:503-505):
-                # norms over all voxels of the un-normalised rows, K4f in norms-only mode
+                # norms over all voxels of the un-normalised rows, K4a / K4f in norms-only mode
                 raw = np.ascontiguousarray(raw_rows_fn(lo, hi), dtype=np.float64)
                 d_raw = self.dev(raw)
                 stats = {}                       # both passes run on the same items: statistics once
-                _, rsq = self.item_fused(d_src, cell_lo, cell_z, d_raw, want_rowsq=True, stats=stats)
+                _, rsq = self.item_fused(d_src, cell_lo, cell_z, d_raw, want_rowsq=True, stats=stats,
+                                         src_ranges=ranges)
                 if project_on is None:
                     rownorm = np.sqrt(rsq.cpu().numpy())
             if raw_rows_fn is not None and project_on is not None:
@@ -501,15 +548,17 @@ class ProjectionEngine:
             else:
                 ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
             vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
-                                       want_rowsq=True, stats=stats if raw_rows_fn is not None else None)
-            nsq[lo:hi] = rsq
+                                       want_rowsq=not use_agg, stats=stats if raw_rows_fn is not None else None,
+                                       src_ranges=ranges if use_agg else None)
+            if not use_agg:
+                nsq[lo:hi] = rsq
             need2 = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
             if need2 == 0:
                 raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
             work2 = torch.empty(need2, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
-                                            k, _ptr(Zt[lo:hi]), _ptr(None), _ptr(work2), need2,
-                                            _stream()), "plsr_latent")
+                                            k, _ptr(Zt[lo:hi]), _ptr(nsq[lo:hi]) if use_agg else _ptr(None),
+                                            _ptr(work2), need2, _stream()), "plsr_latent")
             if on_batch is not None:
                 ev = torch.cuda.Event()
                 ev.record()

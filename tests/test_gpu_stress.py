@@ -68,6 +68,101 @@ def test_fused_items_random_shapes():
                                    err_msg=tag)
 
 
+def _check_items(eng, X, src, cell_lo, zflags, rows, ref, tag, ranges, expect):
+    import torch
+    p, k = X.shape[1], rows.shape[1]
+    S1 = torch.zeros((p, k), dtype=torch.float64, device=eng.device)
+    S2 = torch.zeros_like(S1)
+    vst, rowsq = eng.item_fused(src, cell_lo, zflags, rows, ref=ref, S1=S1, S2=S2, want_vst=True, want_rowsq=True,
+                                src_ranges=ranges)
+    assert eng.last_item_kernel == expect, tag
+    Z = _zscore_items(X, src, cell_lo, zflags)
+    want = np.einsum("bji,biv->bjv", rows, Z)
+    scale = max(np.abs(want).max(), 1e-300)
+    np.testing.assert_allclose(vst.cpu().numpy(), want, rtol=1e-9, atol=1e-10 * scale, err_msg=tag)
+    np.testing.assert_allclose(rowsq.cpu().numpy(), (want ** 2).sum(-1), rtol=1e-9, atol=1e-18 * scale ** 2,
+                               err_msg=tag)
+    d = np.transpose(want, (0, 2, 1)) - ref
+    np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-9, atol=1e-9 * (scale + 1), err_msg=tag)
+    np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-9 * (scale + 1) ** 2,
+                               err_msg=tag)
+
+
+def test_aggregated_items_random_shapes():
+    """K4a (plsr_item_agg: aggregated operators, X in registers, statistics by MFMA) against
+    NumPy on items whose cells draw from their own row ranges, as the reference's bootstrap
+    does: aligned and unaligned cells (several sweeps), cells of one and two rows whose samples
+    are constant (duplicates), a copied block over all rows next to z-scored cells (the
+    multiblock's shape), item counts off the group of four, k in all three tile counts."""
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(77)
+    for trial in range(28):
+        n = int(rs.choice([6, 17, 22, 40, 60, 64, 96, 120, 128]))
+        p = int(rs.choice([1, 15, 64, 65, 129, 300]))
+        k = int(rs.choice([1, 5, 16, 17, 33, 48]))
+        items = int(rs.randint(1, 14))
+        aligned = trial % 3 != 0
+        # z-scored cells: a partition of (a subset of) the source rows
+        ncz = int(rs.randint(1, min(n // 4 if aligned else n, 7) + 1))
+        if aligned:
+            cuts = 4 * np.sort(rs.choice(np.arange(1, n // 4 + 1), size=ncz, replace=False))
+            bounds = np.concatenate(([0], cuts))
+        else:
+            bounds = _cells(rs, n, ncz)
+        task = trial % 4 == 1                  # multiblock: copied block over all rows first
+        src_lo, src_hi, cell_lo, zflags, cols = [], [], [0], [], []
+        if task:
+            src_lo.append(0), src_hi.append(n), zflags.append(0)
+            cell_lo.append(n)
+            cols.append(rs.randint(0, n, size=(items, n)))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if rs.rand() < 0.2 and len(bounds) > 2:
+                continue                        # rows no cell reads
+            cnt = int(hi - lo) if rs.rand() < 0.7 else int(rs.randint(1, 2 * (hi - lo) + 1))
+            src_lo.append(int(lo)), src_hi.append(int(hi)), zflags.append(1)
+            cell_lo.append(cell_lo[-1] + cnt)
+            cols.append(rs.randint(lo, hi, size=(items, cnt)))
+        if not cols:
+            continue
+        src = np.concatenate(cols, axis=1).astype(np.int32)
+        cell_lo = np.array(cell_lo)
+        nz = int(cell_lo[-1])
+        X = rs.randn(n, p) * 2 + rs.randn(1, p) * 10 + 5.0 * (np.arange(n)[:, None] // 7)
+        rows = rs.randn(items, k, nz)
+        ref = rs.randn(p, k)
+        eng = ProjectionEngine(X)
+        tag = f"trial {trial}: n={n} p={p} nz={nz} cells={len(zflags)} k={k} items={items} aligned={aligned}"
+        ranges = (np.array(src_lo), np.array(src_hi))
+        found = eng.source_ranges(src, cell_lo)
+        assert (found[0] >= ranges[0]).all() and (found[1] <= ranges[1]).all(), tag
+        need = eng.lib.plsr_item_agg_workspace_bytes(
+            n, nz, k, (ctypes.c_int32 * len(cell_lo))(*cell_lo), (ctypes.c_int32 * len(zflags))(*zflags),
+            (ctypes.c_int32 * len(zflags))(*src_lo), (ctypes.c_int32 * len(zflags))(*src_hi), len(zflags), items, p,
+            1, 1)
+        _check_items(eng, X, src, cell_lo, np.array(zflags), rows, ref, tag, ranges, "agg" if need else "gather")
+
+
+def test_aggregated_items_reject_rows_outside_their_range():
+    """An item that reads a source row outside its cell's declared range is returned as NaN."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(5)
+    n, p, k = 24, 70, 5
+    X = rs.randn(n, p)
+    cell_lo = np.array([0, 12, 24])
+    src = np.stack([np.concatenate((rs.randint(0, 12, 12), rs.randint(12, 24, 12))) for _ in range(6)]).astype(np.int32)
+    src[4, 3] = 17
+    eng = ProjectionEngine(X)
+    S1 = torch.zeros((p, k), dtype=torch.float64, device=eng.device)
+    S2 = torch.zeros_like(S1)
+    vst, _ = eng.item_fused(src, cell_lo, np.ones(2, int), rs.randn(6, k, 24), S1=S1, S2=S2, want_vst=True,
+                            src_ranges=(np.array([0, 12]), np.array([12, 24])))
+    assert eng.last_item_kernel == "agg"
+    got = vst.cpu().numpy()
+    assert np.isnan(got[4]).any() and not np.isnan(got[[0, 1, 2, 3, 5]]).any()
+    assert np.isnan(S1.cpu().numpy()).any()
+
+
 def test_fused_gram_and_latent_random_shapes():
     import torch
     from plspy_amd import _lib
