@@ -168,6 +168,14 @@ struct AggArgs {
 #endif
 };
 
+// value of the neighbouring lane (lane ^ 1), by DPP quad_perm [1, 0, 3, 2] on the two halves
+__device__ __forceinline__ double swap_pair_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double mfma4_f64(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
@@ -272,15 +280,22 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
       double mf[AG_SRING];
 #pragma unroll
       for (int u = 0; u < AG_SRING; ++u) mf[u] = mp[(size_t)u * 64];
-      double s1c = 0.0, s2c = 0.0;
+      // (two accumulation chains per sum: a chain of dependent 4x4x4 MFMAs exposes its latency every time)
+      double s1a = 0.0, s1b = 0.0, s2a = 0.0, s2b = 0.0;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const double m = mf[f % AG_SRING];
         mf[f % AG_SRING] = mp[(size_t)(f + AG_SRING) * 64];        // (the stream carries AG_SRING steps of padding)
-        s1c = mfma4_f64(m, x[f], s1c);
-        s2c = mfma4_f64(m, x[f] * x[f], s2c);
+        if (f & 1) {
+          s1b = mfma4_f64(m, x[f], s1b);
+          s2b = mfma4_f64(m, x[f] * x[f], s2b);
+        } else {
+          s1a = mfma4_f64(m, x[f], s1a);
+          s2a = mfma4_f64(m, x[f] * x[f], s2a);
+        }
         if ((endm >> f) & 1u) {
           // lane (item g of the group, voxel col): s1c = sum m x', s2c = sum m x'^2 over the cell
+          const double s1c = s1a + s1b, s2c = s2a + s2b;
           const double mu = s1c * rcnt;
           const double var = fma(-s1c, mu, s2c);                 // n_c * variance
           // scipy.stats.zscore's constant-slice rule (sd <= eps |mean|) followed by nan_to_num -> 0
@@ -292,8 +307,7 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
           const double sc = dead ? 0.0 : rsqrt(var);
           st[(zc * 2) * 64 + lane] = sc;
           st[(zc * 2 + 1) * 64 + lane] = dead ? 0.0 : -mu * sc;
-          s1c = 0.0;
-          s2c = 0.0;
+          s1a = s1b = s2a = s2b = 0.0;
           zc = min(zc + 1, AG_MAXZC - 1);
           cnt = ctab[2 * zc];
           rcnt = ctab[2 * zc + 1];
@@ -367,17 +381,33 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
   const int jl = g + 8 * (int)odd;                 // this lane's row within the 16-row tile, for piece h: + 4 h
   const uint32_t loff = (uint32_t)(((int64_t)jl * A.ldv + (v - odd)) * 8);
   const int vcode = (v - odd) + 1 < A.p ? 2 : ((v - odd) < A.p ? 1 : 0);   // both voxels of the pair exist / the first only
-  d2 hold[MC][2];
+  double hold[MC][4];                              // the previous item's VS (acc as it stood)
   int hold_item = -1;
   const char *hold_base = nullptr;                 // (uniform) &vst[hold_item][0][0]
   auto store_piece = [&](int mc, int h) {
+    // even lane: row r = h of its own and its neighbour's voxel; odd lane: row r = 2 + h
+    const double got = swap_pair_f64(odd ? hold[mc][h] : hold[mc][2 + h]);
+    const d2 pc = odd ? (d2){got, hold[mc][2 + h]} : (d2){hold[mc][h], got};
     const int jrow = 16 * mc + 4 * h;
     if (jl + jrow < A.k) {
       char *dst = (char *)hold_base + (int64_t)jrow * A.ldv * 8 + loff;
       if (vcode == 2) {
-        *(d2 *)dst = hold[mc][h];
+        *(d2 *)dst = pc;
       } else if (vcode == 1) {
-        *(double *)dst = hold[mc][h].x;
+        *(double *)dst = pc.x;
+      }
+    }
+  };
+  // the moment sums take the previous item's values one (tile, row) pair per k-step
+  constexpr int MPS = (4 * MC + US - 2) / (US - 1);    // pairs per k-step, from step 1
+  auto moment_pairs = [&](int s_) {
+#pragma unroll
+    for (int u = 0; u < MPS; ++u) {
+      const int idx = (s_ - 1) * MPS + u;
+      if (idx >= 0 && idx < 4 * MC) {
+        const double val = hold[idx >> 2][idx & 3];
+        s1[idx >> 2][idx & 3] += val;
+        if (!(AGG_ABLATE & 16)) s2[idx >> 2][idx & 3] = fma(val, val, s2[idx >> 2][idx & 3]);
       }
     }
   };
@@ -441,24 +471,38 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
       for (int f = 0; f < NF; ++f) {
         const int un = f / US, s_ = f - un * US;                  // unit of the sweep, k-step inside it
         const int ulen = un == NUPS - 1 ? USL : US;
-        // staging of the next unit: piece q is loaded at step sl0 + q and written WDELAY steps later
-        if (!(AGG_ABLATE & 2)) {
-          const int sl0 = un == 0 ? 0 : SLB;
-          const int qw = s_ - sl0 - WDELAY, ql = s_ - sl0;
-          if (qw >= 0 && qw < NQ) nxt[qw * (AG_WAVES * 64)] = park[qw % WDELAY];
-          if (ql >= 0 && ql < NQ) park[ql % WDELAY] = gsrc[ql * (AG_WAVES * 64)];
-        }
+        // The non-MFMA work of a k-step sits in the shadows of the step's own MFMAs (an MFMA holds
+        // the matrix pipe for 64 cycles, the wave is free to issue other instructions meanwhile).
+        // Left to the scheduler, a step was MC MFMAs followed by everything else, the two waves
+        // of a SIMD fell into step with each other and the pipe idled through both waves'
+        // "everything else" (about 120 of 500 cycles per k-step).
+        double znext = 0.0;
 #pragma unroll
-        for (int mc = 0; mc < MC; ++mc) acc[mc] = mfma_f64(fa[s_ % AG_RING][mc], z, acc[mc]);
-        if (s_ + AG_RING < ulen) {
-#pragma unroll
-          for (int mc = 0; mc < MC; ++mc) fa[s_ % AG_RING][mc] = cur[((s_ + AG_RING) * MC + mc) * 64];
+        for (int mc = 0; mc < MC; ++mc) {
+          acc[mc] = mfma_f64(fa[s_ % AG_RING][mc], z, acc[mc]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s_ + AG_RING < ulen) fa[s_ % AG_RING][mc] = cur[((s_ + AG_RING) * MC + mc) * 64];
+          if (mc == 0 && !(AGG_ABLATE & 2)) {
+            // staging of the next unit: piece q is loaded at step sl0 + q and written WDELAY steps later
+            const int sl0 = un == 0 ? 0 : SLB;
+            const int qw = s_ - sl0 - WDELAY, ql = s_ - sl0;
+            if (qw >= 0 && qw < NQ) nxt[qw * (AG_WAVES * 64)] = park[qw % WDELAY];
+            if (ql >= 0 && ql < NQ) park[ql % WDELAY] = gsrc[ql * (AG_WAVES * 64)];
+          }
+          if (mc == (MC > 1 ? 1 : 0) && f + 1 < NF) znext = enter(f + 1);
+          if (mc == MC - 1 && un == 0) {
+            // the previous item's results (first unit of the item only): moment sums from step 1,
+            // stores at k-steps S0 .. S0 + NP - 1
+            if (s_ >= 1 && (s_ - 1) * MPS < 4 * MC) {
+              if (sw == 0 && hold_item >= 0 && moments) moment_pairs(s_);
+            }
+            if (!(AGG_ABLATE & 16) && s_ >= S0 && s_ < S0 + NP) {
+              if (sw == 0 && hold_item >= 0 && A.vst != nullptr) store_piece((s_ - S0) >> 1, (s_ - S0) & 1);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (f + 1 < NF) z = enter(f + 1);
-        // the previous item's results (first unit of the item only): k-steps S0 .. S0 + NP - 1
-        if (!(AGG_ABLATE & 16) && un == 0 && s_ >= S0 && s_ < S0 + NP) {
-          if (sw == 0 && hold_item >= 0 && A.vst != nullptr) store_piece((s_ - S0) >> 1, (s_ - S0) & 1);
-        }
+        z = znext;
         if (s_ == ulen - 1) {
           // unit done: everybody has read it and has written its pieces of the next (LDS only:
           // global stores stay in flight across the barrier)
@@ -487,29 +531,14 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
     t_loop += te0 - tl0;
 #endif
 
-    // ---- item done: acc[mc][r] = VS[j = 16 mc + g + 4 r][voxel col] ----
+    // ---- item done: acc[mc][r] = VS[j = 16 mc + g + 4 r][voxel col]; it is consumed (moment
+    // sums, stores) during the next item's first k-steps ----
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) {
-      double q[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double val = acc[mc][r];
-        if (moments) {
-          s1[mc][r] += val;
-          if (!(AGG_ABLATE & 16)) s2[mc][r] = fma(val, val, s2[mc][r]);
-        }
-        q[r] = vok ? val * val : 0.0;
-      }
-      if (A.vst != nullptr) {
-        const double give0 = odd ? acc[mc][0] : acc[mc][2], give1 = odd ? acc[mc][1] : acc[mc][3];
-        const double got0 = __shfl_xor(give0, 1), got1 = __shfl_xor(give1, 1);
-        hold[mc][0] = odd ? (d2){got0, acc[mc][2]} : (d2){acc[mc][0], got0};
-        hold[mc][1] = odd ? (d2){got1, acc[mc][3]} : (d2){acc[mc][1], got1};
-      }
       if (A.rowsq_part != nullptr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double t = q[r];
+          double t = vok ? acc[mc][r] * acc[mc][r] : 0.0;
           t += __shfl_xor(t, 1);
           t += __shfl_xor(t, 2);
           t += __shfl_xor(t, 4);
@@ -517,6 +546,8 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
           if (col == 0) A.rowsq_part[(tile * A.items + item) * (MC * 16) + mc * 16 + g + 4 * r] = t;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hold[mc][r] = acc[mc][r];
     }
     hold_item = item;
     hold_base = (const char *)A.vst + (int64_t)item * A.k * A.ldv * 8;
@@ -536,6 +567,11 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
     o[6] = t_begin;
   }
 #endif
+  // the last item's values
+  if (moments) {
+#pragma unroll
+    for (int s_ = 1; (s_ - 1) * MPS < 4 * MC; ++s_) moment_pairs(s_);
+  }
   if (A.vst != nullptr && !(AGG_ABLATE & 16)) {
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
   const int item0 = blockIdx.x * IG;
   const int chunk = blockIdx.y;
   constexpr int nrow_x = WV * NI * 16;            // every wave's NI tiles of data rows (zero padded)
-  constexpr int RPP = WV * 2;                     // rows staged per pass (32 voxels per row)
+  constexpr int RPP = WV * 4;                     // rows staged per pass (sixteen threads per row of 32 voxels)
   constexpr int NV = (IG * MC * 16 + RPP - 1) / RPP;   // passes over the VS^T rows
   constexpr int NX = nrow_x / RPP;                     // passes over the X rows
   double *Vs = smem;                              // [IG][MC*16][LV_LD]   VS^T tiles
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
   const int64_t nvt = (A.p + LV_T - 1) / LV_T;
   const int64_t t_lo = (int64_t)chunk * A.tiles_per_chunk;
   const int64_t t_hi = min(nvt, t_lo + A.tiles_per_chunk);
-  const int srow = tid >> 5, svox = tid & 31;
+  // staging: a thread moves two neighbouring voxels of a row per load (16 bytes); a pass of the
+  // workgroup covers RPP rows of the 32-voxel tile
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int srow = tid >> 4, svox = (tid & 15) * 2;
 
   f64x4 acc[IG][MC][NI];
   double nsq[IG][MC];
@@ -69,39 +72,66 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_kernel(LatentArgs A) {
       for (int ni = 0; ni < NI; ++ni) acc[ig][mc][ni] = (f64x4){0.0, 0.0, 0.0, 0.0};
     }
 
-  double pv[NV], px[NX];
-  // Unconditional loads from clamped addresses (a load under a branch costs a branch per load,
-  // a select on the loaded value would make the fetch wait for its own data); what does not
-  // exist -- voxels past p, tiles past the chunk, rows past k / n -- is zeroed when the tile is
-  // parked (pinv remembers the fetched tile's voxel validity).
-  bool pinv = false;
+  // Byte offsets of the rows this thread stages, relative to the first item of the group (VS^T)
+  // and to X: constant over the tiles, 32 bits (the library checks the sizes), so that a load is
+  // a scalar base + this register and the tile loop carries no 64-bit address arithmetic (the
+  // kernel used to spend five vector instructions per MFMA on it).  Rows that do not exist --
+  // latent variables past k, data rows past n, items past the last -- are clamped to rows that
+  // do: what they produce lands in outputs that are never stored.
+  uint32_t offv[NV], offx[NX];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int rr = min(q * RPP + srow, IG * MC * 16 - 1);
+    const int ig = rr / (MC * 16), row = min(rr % (MC * 16), A.k - 1);
+    const int item = min(item0 + ig, A.items - 1) - item0;
+    offv[q] = (uint32_t)((((int64_t)item * A.k + row) * A.ldv + svox) * 8);
+  }
+#pragma unroll
+  for (int q = 0; q < NX; ++q) offx[q] = (uint32_t)(((int64_t)min(q * RPP + srow, A.n - 1) * A.ldx + svox) * 8);
+  const char *vbase = (const char *)(A.vst + (int64_t)item0 * A.k * A.ldv);
+  const char *xbase = (const char *)A.X;
+
+  d2 pv[NV], px[NX];
+  // a tile that is not wholly inside [0, p) and inside the chunk (the last tile of a row, the
+  // prefetch past the chunk's end) takes the slow path: per-voxel clamped loads, missing voxels zeroed
   auto fetch = [&](int64_t vt) {
-    const int64_t vv = vt * LV_T + svox;
-    pinv = vv < A.p && vt < t_hi;
-    const int64_t vc = min(vv, A.p - 1);
+    const bool full = (vt + 1) * LV_T <= A.p && vt < t_hi;        // (uniform)
+    if (full) {
+      const char *bv = vbase + vt * (LV_T * 8), *bx = xbase + vt * (LV_T * 8);
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int rr = min(q * RPP + srow, IG * MC * 16 - 1);  // row of the stacked [IG][MC*16] tile
-      const int ig = rr / (MC * 16), row = min(rr % (MC * 16), A.k - 1);
-      const int item = min(item0 + ig, A.items - 1);        // a short last group recomputes the last item
-      pv[q] = A.vst[((int64_t)item * A.k + row) * A.ldv + vc];
-    }
+      for (int q = 0; q < NV; ++q) pv[q] = *(const d2 *)(bv + offv[q]);
 #pragma unroll
-    for (int q = 0; q < NX; ++q) {
-      const int row = min(q * RPP + srow, A.n - 1);
-      px[q] = A.X[(int64_t)row * A.ldx + vc];
+      for (int q = 0; q < NX; ++q) px[q] = *(const d2 *)(bx + offx[q]);
+    } else {
+      const int64_t v0 = vt * LV_T + svox;
+      const bool ok0 = v0 < A.p && vt < t_hi, ok1 = v0 + 1 < A.p && vt < t_hi;
+      const int64_t c0 = min(v0, A.p - 1) * 8 - (int64_t)svox * 8, c1 = min(v0 + 1, A.p - 1) * 8 - (int64_t)svox * 8;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const double a = *(const double *)(vbase + offv[q] + c0), b = *(const double *)(vbase + offv[q] + c1);
+        pv[q] = (d2){ok0 ? a : 0.0, ok1 ? b : 0.0};
+      }
+#pragma unroll
+      for (int q = 0; q < NX; ++q) {
+        const double a = *(const double *)(xbase + offx[q] + c0), b = *(const double *)(xbase + offx[q] + c1);
+        px[q] = (d2){ok0 ? a : 0.0, ok1 ? b : 0.0};
+      }
     }
   };
   auto park = [&]() {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int rr = q * RPP + srow;
-      if (rr < IG * MC * 16) Vs[rr * LV_LD + svox] = (pinv && rr % (MC * 16) < A.k) ? pv[q] : 0.0;
+      if (rr < IG * MC * 16) {
+        Vs[rr * LV_LD + svox] = pv[q].x;
+        Vs[rr * LV_LD + svox + 1] = pv[q].y;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
       const int row = q * RPP + srow;
-      Xs[row * LV_LD + svox] = (pinv && row < A.n) ? px[q] : 0.0;
+      Xs[row * LV_LD + svox] = px[q].x;
+      Xs[row * LV_LD + svox + 1] = px[q].y;
     }
   };
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,6 +41,7 @@ bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl)
   // eight waves (one tile of data rows each) when there are that many tiles: small
   // accumulators, four waves per SIMD at two workgroups per CU
   pl.WV = (n + 15) / 16 > 4 ? 8 : 4;
+  if (const char *e = getenv("PLSR_LATENT_WV")) pl.WV = atoi(e);   // developer knob (experiments)
   pl.NI = ((n + 15) / 16 + pl.WV - 1) / pl.WV;
   if (pl.MC > 4 || pl.NI > 2) return false;
   // items per workgroup: as many as the accumulators allow (IG * MC * NI tiles of 8 VGPRs)
@@ -48,10 +50,27 @@ bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl)
   pl.ngroups = (items + pl.IG - 1) / pl.IG;
   pl.lds = latent_lds_bytes(pl.MC, pl.NI, pl.IG, pl.WV);
   const int64_t nvt = (p + LV_T - 1) / LV_T;
-  int want = (int)std::max<int64_t>(1, (1024 + pl.ngroups - 1) / pl.ngroups);
-  want = (int)std::min<int64_t>(want, nvt);
-  pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
-  pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
+  // voxel chunks: about 1024 workgroups, and a count whose last round of the chip's resident
+  // workgroups (two per CU with eight waves, LDS permitting) is as full as the others -- 125 groups
+  // x 9 chunks were 2.2 rounds of 512 and ran as three
+  {
+    const int64_t slots = 512;
+    const int lo = (int)std::max<int64_t>(1, (768 + pl.ngroups - 1) / pl.ngroups);
+    const int hi = (int)std::max<int64_t>(lo, (2048 + pl.ngroups - 1) / pl.ngroups);
+    int want = lo;
+    double best = -1.0;
+    for (int c = lo; c <= hi; ++c) {
+      const double rounds = (double)pl.ngroups * c / (double)slots;
+      const double eff = rounds / std::ceil(rounds);
+      if (eff > best + 1e-3) {
+        best = eff;
+        want = c;
+      }
+    }
+    want = (int)std::min<int64_t>(want, nvt);
+    pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
+    pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
+  }
   pl.z_elems = (size_t)pl.nchunk * items * k * n;
   pl.n_elems = (size_t)pl.nchunk * items * k;
   pl.bytes = ((pl.z_elems + pl.n_elems) * sizeof(double) + 511) / 256 * 256;
@@ -98,6 +117,9 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
   LatentPlan pl;
   if (!latent_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
   if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  // the kernel addresses the rows a thread stages by 32-bit byte offsets from a group's first item / from X
+  if ((int64_t)pl.IG * k * ldv * 8 >= ((int64_t)1 << 32) || (int64_t)n * ldx * 8 >= ((int64_t)1 << 32))
+    return PLSR_EUNSUPPORTED;
   LatentArgs a;
   a.X = d_X;
   a.ldx = ldx;
