@@ -315,6 +315,32 @@ int plsr_item_agg(const double *d_X, int64_t ldx, int64_t p, int32_t n, const in
                   double *d_rowsq, void *d_work, size_t work_bytes, void *stream);
 
 /*
+ * ---- K4b: behaviour PLS bootstrap in two stages ---------------------------------
+ * The same VS_b as plsr_item_agg with operator rows  rows_b[j][i] = sum_beh Yz_b[i][beh] *
+ * U[(cell(i), beh)][j]  (behaviour PLS: class_functions.py:185-247 followed by
+ * bootstrap_permutation.py:620), taken in the reference's own two steps instead of one folded
+ * product: R_bc = Yz_bc^T Z_bc per cell (b rows), then VS_b = sum_c U_c^T R_bc -- 2 b n p +
+ * 2 k^2 p flops per item instead of 2 k n p (config 3: 1.3 instead of 2.3 GFLOP).  Two items
+ * share the 16 rows of a stage-1 MFMA tile (b <= 8); the scaled stage-1 accumulators are, in
+ * place, the B operands of stage 2.  All cells are z-scored.
+ *   d_Yz : [items][nz][b] behaviour rows of every item's sample, z-scored within the cells
+ *          (their columns must sum to zero over a cell: the shift of X's z-score then drops out)
+ *   d_U  : [ncell * b][k] left singular vectors, rows ordered (cell, behaviour)
+ *   cell_lo / src_lo / src_hi : HOST arrays as in plsr_item_agg (an item that reads outside its
+ *          ranges comes out as NaN); d_S1 / d_S2 / d_ref / d_vst as in plsr_item_fused
+ * b <= 16, k <= 48, ncell <= 16, and (cells x k-steps of the longest cell) must fit one of the
+ * register layouts (5 x 6, 8 x 4, 4 x 8, 2 x 16): plsr_item_beh_workspace_bytes returns 0 otherwise.
+ */
+size_t plsr_item_beh_workspace_bytes(int32_t n, int32_t nz, int32_t b, int32_t k, const int32_t *cell_lo,
+                                     const int32_t *src_lo, const int32_t *src_hi, int32_t ncell,
+                                     int32_t items, int64_t p, int32_t want_moments);
+int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src, int32_t nz,
+                  const int32_t *cell_lo, const int32_t *src_lo, const int32_t *src_hi, int32_t ncell,
+                  const double *d_Yz, int32_t b, const double *d_U, int32_t items, int32_t k,
+                  const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv, void *d_work,
+                  size_t work_bytes, void *stream);
+
+/*
  * Multiblock operator rows for plsr_item_fused, formed on the device from the
  * un-normalised rows and the squared row norms plsr_item_fused returned for them
  * (two-phase row normalisation, class_functions.py:503-505, then `@ U`, :620):

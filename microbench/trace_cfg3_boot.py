@@ -23,6 +23,13 @@ def item_fused(*a, **kw):
     e0.record(); out = orig_item_fused(*a, **kw); e1.record()
     log.append(("item_fused", t0, time.perf_counter(), e0, e1)); return out
 eng.item_fused = item_fused
+orig_item_beh = eng.item_beh
+def item_beh(*a, **kw):
+    t0 = time.perf_counter(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); out = orig_item_beh(*a, **kw); e1.record()
+    if out is not None: log.append(("item_beh", t0, time.perf_counter(), e0, e1))
+    return out
+eng.item_beh = item_beh
 lat = eng.lib.plsr_latent
 class L:
     def __getattr__(self, name): return getattr(eng_lib, name)

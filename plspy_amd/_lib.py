@@ -53,6 +53,9 @@ SIGNATURES = {
                                              c_i32]),
     "plsr_item_agg": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
                               c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_item_beh_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32]),
+    "plsr_item_beh": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
+                              c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "plsr_gram_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64]),
     "plsr_gram_fused": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32,
                                 c_vp, c_vp, c_sz, c_vp]),

@@ -544,7 +544,8 @@ class _ResampleTestPLS(ResampleTest):
             Lt = np.take_along_axis(zt, mine[a:z][:, None, :].astype(np.int64), axis=2)
             LVc[a:z] = cf.lvcorr_from_latents(Lt, cf.zscore_cells(Y[mine[a:z]], bounds), bounds)
 
-        res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch)
+        res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch,
+                             beh=(lambda a, z: cf.zscore_cells(Y[mine[a:z]], bounds), U))
         std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z                                      # :723-724

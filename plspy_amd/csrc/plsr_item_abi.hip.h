@@ -5,6 +5,7 @@
 #include "plsr_item.hip.h"
 #include "plsr_fused.hip.h"
 #include "plsr_agg.hip.h"
+#include "plsr_beh.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -770,6 +771,178 @@ extern "C" int plsr_item_agg(const double *d_X, int64_t ldx, int64_t p, int32_t 
                        (const double *)a.rowsq_part, lvl2, E, (int)pl.ntile, 64);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
                        (const double *)lvl2, d_rowsq, E, pl.nchunk, pl.nchunk);
+  }
+  return launch_ok();
+}
+
+// ---------------------------------------------------------------------------
+// K4b: behaviour PLS bootstrap in two stages (plsr_beh.hip.h)
+// ---------------------------------------------------------------------------
+namespace {
+struct BehPlan {
+  int CSMAX, NCMAX, BP, IP, MC, cs, nsplit, per, ngrp, nsg, unit, unit_p;
+  int64_t nwg;
+  size_t lds;
+  size_t o_a1, o_mfrag, o_u2, o_mom, bytes;
+};
+
+bool beh_plan(int32_t n, int32_t nz, int32_t b, int32_t k, const int32_t *cell_lo, const int32_t *src_lo,
+              const int32_t *src_hi, int32_t ncell, int32_t items, int64_t p, bool moments, BehPlan &pl) {
+  if (n <= 0 || nz <= 0 || b <= 0 || b > 16 || k <= 0 || k > 48 || items <= 0 || p <= 0) return false;
+  if (!cell_lo || !src_lo || !src_hi || ncell <= 0 || ncell > AG_MAXZC) return false;
+  if (cell_lo[0] != 0 || cell_lo[ncell] != nz) return false;
+  int cs = 0;
+  for (int c = 0; c < ncell; ++c) {
+    if (cell_lo[c + 1] <= cell_lo[c] || src_lo[c] < 0 || src_hi[c] > n || src_hi[c] <= src_lo[c]) return false;
+    cs = std::max(cs, (src_hi[c] - src_lo[c] + 3) / 4);
+  }
+  // register layouts item_beh_kernel is instantiated for: (k-steps per cell, cells)
+  static const int lay[][2] = {{5, 6}, {8, 4}, {4, 8}, {2, 16}};
+  pl.CSMAX = 0;
+  for (auto &l : lay)
+    if (cs <= l[0] && ncell <= l[1]) {
+      pl.CSMAX = l[0];
+      pl.NCMAX = l[1];
+      break;
+    }
+  if (!pl.CSMAX) return false;
+  pl.cs = cs;
+  pl.BP = b <= 8 ? 8 : 16;
+  pl.IP = 16 / pl.BP;
+  pl.MC = (k + 15) / 16;
+  pl.ngrp = (items + pl.IP - 1) / pl.IP;
+  pl.nsg = (items + 3) / 4;
+  pl.unit = ncell * cs * 64;
+  pl.unit_p = (pl.unit + 511) / 512 * 512;
+  pl.nwg = (p + 16 * BH_WAVES - 1) / (16 * BH_WAVES);
+  pl.nsplit = 1;
+  {
+    double best = 0.0;
+    for (int ns = 1; ns <= std::min(8, pl.nsg); ++ns) {
+      const double rounds = (double)pl.nwg * ns / 512.0;
+      const double eff = rounds / std::ceil(rounds);
+      if (eff > best + 1e-9) {
+        best = eff;
+        pl.nsplit = ns;
+      }
+      if (eff >= 0.94) break;
+    }
+  }
+  pl.per = (pl.nsg + pl.nsplit - 1) / pl.nsplit * 4;
+  pl.nsplit = (items + pl.per - 1) / pl.per;
+  pl.lds = ((size_t)ncell * (pl.BP / 4) * pl.MC * 64 + (size_t)2 * pl.unit_p + (size_t)BH_WAVES * ncell * 64) *
+           sizeof(double);
+  if (pl.lds > 160 * 1024) return false;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  pl.o_a1 = take(((size_t)pl.ngrp * pl.unit + 2 * pl.unit_p) * sizeof(double));   // + what the staging reads ahead
+  pl.o_mfrag = take((size_t)pl.nsg * ncell * cs * 64 * sizeof(double));
+  pl.o_u2 = take((size_t)ncell * (pl.BP / 4) * pl.MC * 64 * sizeof(double));
+  pl.o_mom = take(moments ? (size_t)2 * pl.nsplit * p * k * sizeof(double) : 0);
+  pl.bytes = off;
+  return true;
+}
+
+template <int CSMAX, int NCMAX>
+int run_beh(const BehArgs &a, const BehPlan &pl, hipStream_t st) {
+  auto launch = [&](auto kern) {
+    if (pl.lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+      return (int)PLSR_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)pl.nwg, (unsigned)pl.nsplit), dim3(BH_WAVES * 64), pl.lds, st, a);
+    return launch_ok();
+  };
+  return pl.BP == 8 ? launch(item_beh_kernel<CSMAX, NCMAX, 8>) : launch(item_beh_kernel<CSMAX, NCMAX, 16>);
+}
+}  // namespace
+
+extern "C" size_t plsr_item_beh_workspace_bytes(int32_t n, int32_t nz, int32_t b, int32_t k, const int32_t *cell_lo,
+                                                const int32_t *src_lo, const int32_t *src_hi, int32_t ncell,
+                                                int32_t items, int64_t p, int32_t want_moments) {
+  BehPlan pl;
+  return beh_plan(n, nz, b, k, cell_lo, src_lo, src_hi, ncell, items, p, want_moments != 0, pl) ? pl.bytes : 0;
+}
+
+extern "C" int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src, int32_t nz,
+                             const int32_t *cell_lo, const int32_t *src_lo, const int32_t *src_hi, int32_t ncell,
+                             const double *d_Yz, int32_t b, const double *d_U, int32_t items, int32_t k,
+                             const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv,
+                             void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_src || !d_Yz || !d_U || !d_work || !cell_lo || !src_lo || !src_hi || ldx < p) return PLSR_EINVAL;
+  if ((d_S1 == nullptr) != (d_S2 == nullptr) || (d_vst && ldv < p)) return PLSR_EINVAL;
+  if (d_vst && (12 * ldv + p) * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;   // 32-bit lane offsets of the stores
+  BehPlan pl;
+  if (!beh_plan(n, nz, b, k, cell_lo, src_lo, src_hi, ncell, items, p, d_S1 != nullptr, pl)) return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char *w = (char *)d_work;
+
+  BehMetaArgs ma;
+  ma.Yz = d_Yz;
+  ma.U = d_U;
+  ma.src = d_src;
+  ma.items = items;
+  ma.nz = nz;
+  ma.b = b;
+  ma.k = k;
+  ma.ncell = ncell;
+  ma.cs = pl.cs;
+  ma.CSMAX = pl.CSMAX;
+  ma.BP = pl.BP;
+  ma.IP = pl.IP;
+  ma.MC = pl.MC;
+  for (int c = 0; c < ncell; ++c) {
+    ma.cell_lo[c] = cell_lo[c];
+    ma.src_lo[c] = src_lo[c];
+    ma.src_hi[c] = src_hi[c];
+  }
+  ma.cell_lo[ncell] = cell_lo[ncell];
+  ma.a1 = (double *)(w + pl.o_a1);
+  ma.mfrag = (double *)(w + pl.o_mfrag);
+  ma.u2 = (double *)(w + pl.o_u2);
+  const int64_t total = (int64_t)pl.ngrp * pl.unit + (int64_t)pl.nsg * ncell * pl.cs * 64 +
+                        (int64_t)ncell * (pl.BP / 4) * pl.MC * 64;
+  hipLaunchKernelGGL(beh_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ma);
+  hipLaunchKernelGGL(beh_check_kernel, dim3((unsigned)(((int64_t)items * nz + 255) / 256)), dim3(256), 0, st, ma);
+
+  BehArgs a;
+  a.X = d_X;
+  a.ldx = ldx;
+  a.p = p;
+  a.n = n;
+  a.items = items;
+  a.k = k;
+  a.per = pl.per;
+  a.ncell = ncell;
+  a.cs = pl.cs;
+  a.MC = pl.MC;
+  for (int c = 0; c < ncell; ++c) {
+    a.src_lo[c] = src_lo[c];
+    a.src_hi[c] = src_hi[c];
+    a.cnt[c] = (double)(cell_lo[c + 1] - cell_lo[c]);
+    a.rcnt[c] = 1.0 / a.cnt[c];
+  }
+  a.a1 = ma.a1;
+  a.mfrag = ma.mfrag;
+  a.u2 = ma.u2;
+  a.S1 = d_S1 ? (double *)(w + pl.o_mom) : nullptr;
+  a.S2 = d_S1 ? a.S1 + (size_t)pl.nsplit * p * k : nullptr;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  int rc = PLSR_EUNSUPPORTED;
+  if (pl.CSMAX == 5) rc = run_beh<5, 6>(a, pl, st);
+  if (pl.CSMAX == 8) rc = run_beh<8, 4>(a, pl, st);
+  if (pl.CSMAX == 4) rc = run_beh<4, 8>(a, pl, st);
+  if (pl.CSMAX == 2) rc = run_beh<2, 16>(a, pl, st);
+  if (rc) return rc;
+  if (d_S1) {
+    const int64_t cnt = p * k;
+    hipLaunchKernelGGL(moment_unshift_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_S1, d_S2,
+                       (const double *)a.S1, (const double *)a.S2, d_ref, cnt, pl.nsplit, (double)items);
   }
   return launch_ok();
 }

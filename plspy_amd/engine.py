@@ -80,11 +80,24 @@ class ProjectionEngine:
         self.n, self.p = self.X.shape
         self.work_limit = int(work_limit) if work_limit is not None else DEFAULT_WORK_LIMIT
         self._lanes = {}
+        self._pool = {}
         self._tail = None
         self._h2d = None
         self._d2h = None
 
     # -- helpers -----------------------------------------------------------
+    def _buf(self, name, nbytes):
+        """Scratch that lives with the engine (bytes, grown on demand).  The batches of a phase run
+        on one stream, so they can share one buffer of each kind; allocating per batch let torch's
+        caching allocator split a cached 9.6 GB block for a smaller request now and then, and the
+        next batch paid a fresh hipMalloc plus the first touch of its pages (one 35 ms kernel in
+        every dozen)."""
+        t = self._pool.get(name)
+        if t is None or t.numel() < nbytes:
+            self._pool[name] = t = None
+            t = self._pool[name] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return t
+
     def dev(self, a, dtype=torch.float64):
         """Device copy of a host array (or the tensor itself if it is already
         there).  Host arrays are uploaded on a dedicated copy stream: a pageable
@@ -416,7 +429,7 @@ class ProjectionEngine:
                                                       int(moments), int(rowsq))
 
     def item_fused(self, src, cell_lo, cell_z, rows, ref=None, S1=None, S2=None, want_vst=False,
-                   want_rowsq=False, stats=None, src_ranges=None):
+                   want_rowsq=False, stats=None, src_ranges=None, pool=False):
         """K4a / K4f: VS_b = rows_b @ Z_b for every item without materialising Z_b
         (Z_b = X[src_b] z-scored within the cells flagged in cell_z).
         rows (items, k, nz).  S1 / S2 (p, k) are accumulated into when given.
@@ -441,9 +454,9 @@ class ProjectionEngine:
                                                           int(S1 is not None), int(want_rowsq))
             if need:
                 self.last_item_kernel = "agg"
-                work = torch.empty(need, dtype=torch.uint8, device=self.device)
+                work = self._buf("k4work", need) if pool else torch.empty(need, dtype=torch.uint8, device=self.device)
                 refd = self.dev(ref)
-                vst = torch.empty((items, k, self.p), dtype=torch.float64, device=self.device) if want_vst else None
+                vst = self._vst(items, k, pool) if want_vst else None
                 k16 = (k + 15) // 16 * 16
                 rowsq = torch.empty((items, k16), dtype=torch.float64, device=self.device) if want_rowsq else None
                 _lib.check(self.lib.plsr_item_agg(
@@ -456,9 +469,9 @@ class ProjectionEngine:
                                                         int(S1 is not None), int(want_rowsq))
         if need == 0:
             raise _lib.PlsrError(f"plsr_item_fused: unsupported shape n={self.n} nz={nz} k={k} ncell={ncell}")
-        work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        work = self._buf("k4work", need) if pool else torch.empty(need, dtype=torch.uint8, device=self.device)
         refd = self.dev(ref)
-        vst = torch.empty((items, k, self.p), dtype=torch.float64, device=self.device) if want_vst else None
+        vst = self._vst(items, k, pool) if want_vst else None
         k16 = (k + 15) // 16 * 16
         rowsq = torch.empty((items, k16), dtype=torch.float64, device=self.device) if want_rowsq else None
         sc = sh = None
@@ -476,8 +489,39 @@ class ProjectionEngine:
             _stream()), "plsr_item_fused")
         return vst, (rowsq[:, :k] if want_rowsq else None)
 
+    def _vst(self, items, k, pool):
+        if not pool:
+            return torch.empty((items, k, self.p), dtype=torch.float64, device=self.device)
+        return self._buf("vst", items * k * self.p * 8)[:items * k * self.p * 8].view(torch.float64).view(items, k, self.p)
+
+    def item_beh(self, src, cell_lo, ranges, Yz, U, ref=None, S1=None, S2=None, want_vst=True, pool=False):
+        """K4b: VS_b of behaviour PLS in two stages (plsr_item_beh), or None when the shape is not
+        served.  src (items, nz), Yz (items, nz, b) z-scored within the cells, U (ncell * b, k)."""
+        d_src = self.dev(src, torch.int32)
+        d_Yz = self.dev(Yz)
+        d_U = self.dev(U)
+        items, nz, b = d_Yz.shape
+        k = int(d_U.shape[1])
+        ncell = len(cell_lo) - 1
+        lo = (ctypes.c_int32 * (ncell + 1))(*[int(x) for x in cell_lo])
+        slo = (ctypes.c_int32 * ncell)(*[int(x) for x in ranges[0]])
+        shi = (ctypes.c_int32 * ncell)(*[int(x) for x in ranges[1]])
+        need = self.lib.plsr_item_beh_workspace_bytes(self.n, nz, b, k, lo, slo, shi, ncell, items, self.p,
+                                                      int(S1 is not None))
+        if not need:
+            return None
+        self.last_item_kernel = "beh"
+        work = self._buf("k4work", need) if pool else torch.empty(need, dtype=torch.uint8, device=self.device)
+        refd = self.dev(ref)
+        vst = self._vst(items, k, pool) if want_vst else None
+        _lib.check(self.lib.plsr_item_beh(
+            _ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_src), nz, lo, slo, shi, ncell, _ptr(d_Yz), b,
+            _ptr(d_U), items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p, _ptr(work), need, _stream()),
+            "plsr_item_beh")
+        return vst
+
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
-                   on_batch=None, project_on=None):
+                   on_batch=None, project_on=None, beh=None):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -535,7 +579,7 @@ class ProjectionEngine:
                 d_raw = self.dev(raw)
                 stats = {}                       # both passes run on the same items: statistics once
                 _, rsq = self.item_fused(d_src, cell_lo, cell_z, d_raw, want_rowsq=True, stats=stats,
-                                         src_ranges=ranges)
+                                         src_ranges=ranges, pool=True)
                 if project_on is None:
                     rownorm = np.sqrt(rsq.cpu().numpy())
             if raw_rows_fn is not None and project_on is not None:
@@ -545,17 +589,29 @@ class ProjectionEngine:
                 _lib.check(self.lib.plsr_scale_project_rows(_ptr(d_raw), _ptr(rsq), rsq.stride(0), _ptr(d_U), cnt,
                                                             m, nz, k, _ptr(ops), _stream()),
                            "plsr_scale_project_rows")
+            elif beh is not None and self.lib.plsr_item_beh_workspace_bytes(
+                    self.n, nz, int(np.shape(beh[1])[0]) // ncell, k,
+                    (ctypes.c_int32 * (ncell + 1))(*[int(x) for x in cell_lo]),
+                    (ctypes.c_int32 * ncell)(*[int(x) for x in ranges[0]]),
+                    (ctypes.c_int32 * ncell)(*[int(x) for x in ranges[1]]), ncell, cnt, self.p, 1):
+                ops = None                       # (the two-stage kernel serves: no dense operator rows)
             else:
                 ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
-            vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
-                                       want_rowsq=not use_agg, stats=stats if raw_rows_fn is not None else None,
-                                       src_ranges=ranges if use_agg else None)
+            vst = None
+            if beh is not None and raw_rows_fn is None:
+                # behaviour PLS: the two-stage kernel takes the z-scored behaviour rows and U themselves
+                vst = self.item_beh(d_src, cell_lo, ranges, beh[0](lo, hi), beh[1], ref=refd, S1=S1, S2=S2, pool=True)
+                use_agg = use_agg or vst is not None        # (column norms from the latent kernel)
+            if vst is None:
+                vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
+                                           want_rowsq=not use_agg, stats=stats if raw_rows_fn is not None else None,
+                                           src_ranges=ranges if use_agg else None, pool=True)
             if not use_agg:
                 nsq[lo:hi] = rsq
             need2 = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
             if need2 == 0:
                 raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
-            work2 = torch.empty(need2, dtype=torch.uint8, device=self.device)
+            work2 = self._buf("k5work", need2)
             _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
                                             k, _ptr(Zt[lo:hi]), _ptr(nsq[lo:hi]) if use_agg else _ptr(None),
                                             _ptr(work2), need2, _stream()), "plsr_latent")

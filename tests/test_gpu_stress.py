@@ -142,6 +142,62 @@ def test_aggregated_items_random_shapes():
         _check_items(eng, X, src, cell_lo, np.array(zflags), rows, ref, tag, ranges, "agg" if need else "gather")
 
 
+def test_two_stage_behaviour_items_random_shapes():
+    """K4b (plsr_item_beh: behaviour PLS in two stages, two items per stage-1 MFMA tile, scaled
+    accumulators as the B operand of the projection) against NumPy: cells of unequal, unaligned
+    sizes in all four register layouts, 1 .. 16 behaviours, samples larger and smaller than their
+    source range, constant samples in small cells, item counts off the pairs and the groups of four."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(31)
+    shapes = [(6, 20, 8), (6, 17, 3), (4, 31, 8), (3, 9, 16), (8, 13, 5), (8, 16, 1), (12, 7, 4), (16, 5, 2),
+              (2, 2, 2), (1, 30, 11), (5, 8, 9)]
+    for trial, (ncell, crow, b) in enumerate(shapes):
+        sizes = rs.randint(max(1, crow - 3), crow + 1, size=ncell)          # source rows per cell
+        src_lo = np.concatenate(([0], np.cumsum(sizes)[:-1])) + rs.randint(0, 3)
+        src_hi = src_lo + sizes
+        n = int(src_hi[-1] + rs.randint(0, 4))
+        p = int(rs.choice([1, 15, 64, 65, 130, 257]))
+        items = int(rs.randint(1, 12))
+        k = min(48, ncell * b)
+        cnts = [int(sz if rs.rand() < 0.6 else rs.randint(1, 2 * sz + 1)) for sz in sizes]
+        cell_lo = np.concatenate(([0], np.cumsum(cnts)))
+        nz = int(cell_lo[-1])
+        src = np.concatenate([rs.randint(lo, hi, size=(items, c)) for lo, hi, c in zip(src_lo, src_hi, cnts)],
+                             axis=1).astype(np.int32)
+        X = rs.randn(n, p) * 2 + rs.randn(1, p) * 10 + 3.0 * (np.arange(n)[:, None] // 5)
+        Y = rs.randn(items, nz, b)
+        Yz = np.empty_like(Y)
+        for lo, hi in zip(cell_lo[:-1], cell_lo[1:]):                       # z-scored within cells (sum 0)
+            blk = Y[:, lo:hi]
+            sd = blk.std(1, keepdims=True)
+            Yz[:, lo:hi] = np.where(sd > 0, (blk - blk.mean(1, keepdims=True)) / np.where(sd > 0, sd, 1), 0.0)
+        U = rs.randn(ncell * b, k)
+        ref = rs.randn(p, k)
+        eng = ProjectionEngine(X)
+        tag = f"trial {trial}: cells={ncell} rows~{crow} b={b} n={n} p={p} nz={nz} k={k} items={items}"
+        S1 = torch.zeros((p, k), dtype=torch.float64, device=eng.device)
+        S2 = torch.zeros_like(S1)
+        vst = eng.item_beh(src, cell_lo, (src_lo, src_hi), Yz, U, ref=ref, S1=S1, S2=S2)
+        assert vst is not None, tag
+        rows = np.zeros((items, k, nz))
+        for c, (lo, hi) in enumerate(zip(cell_lo[:-1], cell_lo[1:])):
+            rows[:, :, lo:hi] = np.einsum("bie,ej->bji", Yz[:, lo:hi], U[c * b:(c + 1) * b])
+        Z = _zscore_items(X, src, cell_lo, np.ones(ncell, int))
+        want = np.einsum("bji,biv->bjv", rows, Z)
+        scale = max(np.abs(want).max(), 1e-300)
+        np.testing.assert_allclose(vst.cpu().numpy(), want, rtol=1e-9, atol=1e-10 * scale, err_msg=tag)
+        d = np.transpose(want, (0, 2, 1)) - ref
+        np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-9, atol=1e-9 * (scale + 1), err_msg=tag)
+        np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-9 * (scale + 1) ** 2,
+                                   err_msg=tag)
+    # a row outside its cell's range poisons its item
+    src[0, 0] = (src_hi[0] + 1) % n if ncell > 1 else src[0, 0]
+    if ncell > 1 and not (src_lo[0] <= src[0, 0] < src_hi[0]):
+        got = eng.item_beh(src, cell_lo, (src_lo, src_hi), Yz, U).cpu().numpy()
+        assert np.isnan(got[0]).any()
+
+
 def test_aggregated_items_reject_rows_outside_their_range():
     """An item that reads a source row outside its cell's declared range is returned as NaN."""
     import torch
