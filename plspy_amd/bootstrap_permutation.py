@@ -509,7 +509,8 @@ class _ResampleTestPLS(ResampleTest):
         else:
             S1, S2 = res["S1"], res["S2"]
         sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)                  # :695, :701
-        return sd.cpu().numpy(), ratio.cpu().numpy(), per_resample
+        sd_h, ratio_h = eng.fetch_async([sd, ratio]).get()                     # (page-locked buffers, see engine)
+        return sd_h, ratio_h, per_resample
 
     def _boot_rb(self, U, s, V, niter, lvcorrs_orig, CI):
         """bootstrap_permutation.py:467-766 for rb."""

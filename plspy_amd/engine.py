@@ -551,16 +551,24 @@ class ProjectionEngine:
         ncell = len(cell_z)
         per_item = (2 * ncell + k + 4) * self.p * 8 + 2 * k * nz * 8
         step = int(max(1, min(R, (self.work_limit // 2) // per_item)))
-        pending = None
+        pending = []
 
         def deliver(job):
             blo, bhi, ev = job
             if self._d2h is None:
                 self._d2h = _side_stream(self.device, "d2h")
+            # into page-locked buffers (torch's caching host allocator recycles them): a copy into
+            # fresh pageable memory makes the runtime lock and unlock those pages for the transfer,
+            # i.e. update the GPU's page tables while the next batch's kernels run
             with torch.cuda.stream(self._d2h):            # waits for that batch only, not for the stream's tail
                 self._d2h.wait_event(ev)
-                zt_h = Zt[blo:bhi].to("cpu")
-                nsq_h = nsq[blo:bhi].to("cpu")
+                zt_h = torch.empty(Zt[blo:bhi].shape, dtype=Zt.dtype, pin_memory=True)
+                nsq_h = torch.empty(nsq[blo:bhi].shape, dtype=nsq.dtype, pin_memory=True)
+                zt_h.copy_(Zt[blo:bhi], non_blocking=True)
+                nsq_h.copy_(nsq[blo:bhi], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._d2h)
+            done.synchronize()
             on_batch(blo, bhi, zt_h.numpy(), nsq_h.numpy())
 
         # the cells of a bootstrap sample read fixed ranges of source rows: aggregated-operator
@@ -618,11 +626,16 @@ class ProjectionEngine:
             if on_batch is not None:
                 ev = torch.cuda.Event()
                 ev.record()
-                if pending is not None:
-                    deliver(pending)
-                pending = (lo, hi, ev)
-        if pending is not None:
-            deliver(pending)
+                pending.append((lo, hi, ev))
+                # Two batches stay enqueued behind the one the device runs: the host consumes batch
+                # i - 2 while batch i - 1 runs and batch i waits.  With one batch of slack a late host
+                # (a slow on_batch) left the device idle for a fraction of a millisecond now and then
+                # -- and a device that has idled drops its clocks: the next kernel then ran 20-40 ms
+                # instead of 6 (the "sporadic slow launch" of the kernel trace).
+                while len(pending) > 2:
+                    deliver(pending.pop(0))
+        while pending:
+            deliver(pending.pop(0))
         return {"S1": S1, "S2": S2, "S12": S12, "Zt": Zt, "nsq": nsq, "R": R}
 
     def eigh(self, G, off, k, init=None, relative=False):
