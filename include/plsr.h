@@ -368,6 +368,25 @@ int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     size_t work_bytes, void *stream);
 
 /*
+ * ---- F4: the upstream feed, X built on the device ---------------------------------
+ * plspy/io/io.py:427-460 (apply_mask_matrices: `m[np.broadcast_to(mask, m.shape)]` -- for every
+ * time point the voxels the mask selects, in C order) and :680-698 (concat_flatten_all_groups:
+ * all subjects stacked, one row each), without the masked copies on the host:
+ *   plsr_mask_indices    stream compaction of the mask: d_idx[j] = flat index of the j-th selected
+ *                        voxel (ascending), *d_count = their number (device int64).  d_mask: nvox bytes.
+ *   plsr_mask_apply_rows d_out[r][j] = d_in[r][d_idx[j]] for nrows rows (time points of a subject's
+ *                        volume, row stride ld_in) into rows of X (row stride ld_out, fp64); the
+ *                        source is fp64 or fp32 (in_is_f32).  nrows <= 65535.
+ * HBM-bound byte work; the reference's own property for these two functions is the round trip of
+ * plspy/tests/test_io.py:8-36 (tests/test_gpu_io.py).
+ */
+size_t plsr_mask_indices_workspace_bytes(int64_t nvox);
+int plsr_mask_indices(const uint8_t *d_mask, int64_t nvox, int64_t *d_idx, int64_t *d_count, void *d_work,
+                      size_t work_bytes, void *stream);
+int plsr_mask_apply_rows(const void *d_in, int32_t in_is_f32, int64_t ld_in, int64_t nrows, const int64_t *d_idx,
+                         int64_t nsel, double *d_out, int64_t ld_out, void *stream);
+
+/*
  * ---- host: bit-exact NumPy legacy RandomState draws -------------------------
  * (no GPU involved; these run wherever the library loads).  key[624] / *pos are
  * np.random.get_state()[1:3]; they come back advanced so that

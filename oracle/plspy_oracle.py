@@ -754,3 +754,37 @@ def summarise_split_half(u, v, u0, v0, lv, CI):
     out["pls_dist_u"], out["pls_dist_v"] = u, v
     out["pls_dist_null_u"], out["pls_dist_null_v"] = u0, v0
     return out
+
+
+# ---------------------------------------------------------------------------
+# upstream feed (plspy/io/io.py) -- the reference module imports nibabel at its top and cannot be
+# imported here: these restatements are NOT pinned by reference-generated fixtures ("parity
+# unpinned"); they are checked against the reference's own round-trip property (tests/test_io.py:8-36)
+# ---------------------------------------------------------------------------
+def io_create_threshold_mask_from_matrices(matrices, threshold=0.15):
+    """io.py:353-398: True where the mean over subjects of the time means exceeds
+    threshold * (max - min) + min."""
+    if threshold < 0 or threshold > 1:
+        raise ValueError(f"threshold must be greater than 0 or less than 1. Value passed in : {threshold}")
+    mats = np.array(matrices)
+    mean_all = np.mean(np.mean(mats, axis=1), axis=0)
+    cond = mean_all > (threshold * (np.max(mean_all) - np.min(mean_all)) + np.min(mean_all))
+    return np.ma.masked_where(cond, mean_all).mask
+
+
+def io_apply_mask_matrices(matrices, mask):
+    """io.py:427-460: m[np.broadcast_to(mask, m.shape)] for every matrix."""
+    return [m[np.broadcast_to(mask, m.shape)] for m in matrices]
+
+
+def io_concat_flatten_all_groups(groups_list):
+    """io.py:680-698."""
+    full = np.concatenate(groups_list, axis=0)
+    return full.reshape(full.shape[0], -1)
+
+
+def io_remap_vectorized_subject_to_4d(vector, mask, original_shape):
+    """io.py:701-760: the masked vector back in its (time, x, y, z) volume, zeros elsewhere."""
+    out = np.zeros(original_shape)
+    out[:, mask == True] = vector.reshape(original_shape[0], -1)      # noqa: E712
+    return out

@@ -64,6 +64,9 @@ SIGNATURES = {
     "plsr_latent_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
     "plsr_latent": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz,
                             c_vp]),
+    "plsr_mask_indices_workspace_bytes": (c_sz, [c_i64]),
+    "plsr_mask_indices": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_mask_apply_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "plsr_rng_permutation": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "plsr_rng_task_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "plsr_rng_bootstraps": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -6,6 +6,7 @@
 #include "plsr_fused.hip.h"
 #include "plsr_agg.hip.h"
 #include "plsr_beh.hip.h"
+#include "plsr_io.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -944,5 +945,43 @@ extern "C" int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t 
     hipLaunchKernelGGL(moment_unshift_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_S1, d_S2,
                        (const double *)a.S1, (const double *)a.S2, d_ref, cnt, pl.nsplit, (double)items);
   }
+  return launch_ok();
+}
+
+// ---------------------------------------------------------------------------
+// F4: X built on the device (plsr_io.hip.h)
+// ---------------------------------------------------------------------------
+extern "C" size_t plsr_mask_indices_workspace_bytes(int64_t nvox) {
+  if (nvox <= 0) return 0;
+  return (size_t)((nvox + IO_BLOCK - 1) / IO_BLOCK + 1) * sizeof(int64_t);
+}
+
+extern "C" int plsr_mask_indices(const uint8_t *d_mask, int64_t nvox, int64_t *d_idx, int64_t *d_count, void *d_work,
+                                 size_t work_bytes, void *stream) {
+  if (!d_mask || !d_idx || !d_count || !d_work || nvox <= 0) return PLSR_EINVAL;
+  if (work_bytes < plsr_mask_indices_workspace_bytes(nvox)) return PLSR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = (nvox + IO_BLOCK - 1) / IO_BLOCK;
+  int64_t *cnt = (int64_t *)d_work;
+  hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(IO_THREADS), 0, st, d_mask, nvox, cnt);
+  hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(IO_THREADS), 0, st, cnt, nb, d_count);
+  hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)nb), dim3(IO_THREADS), 0, st, d_mask, nvox,
+                     (const int64_t *)cnt, d_idx);
+  return launch_ok();
+}
+
+extern "C" int plsr_mask_apply_rows(const void *d_in, int32_t in_is_f32, int64_t ld_in, int64_t nrows,
+                                    const int64_t *d_idx, int64_t nsel, double *d_out, int64_t ld_out, void *stream) {
+  if (nrows < 0 || nsel < 0 || ld_out < nsel || nrows > 65535) return PLSR_EINVAL;
+  if (nrows == 0 || nsel == 0) return PLSR_OK;                 // (an empty mask: nothing to move)
+  if (!d_in || !d_idx || !d_out) return PLSR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((nsel + IO_THREADS - 1) / IO_THREADS), (unsigned)nrows);
+  if (in_is_f32)
+    hipLaunchKernelGGL(mask_apply_kernel<float>, grid, dim3(IO_THREADS), 0, st, (const float *)d_in, ld_in, d_idx, nsel,
+                       d_out, ld_out);
+  else
+    hipLaunchKernelGGL(mask_apply_kernel<double>, grid, dim3(IO_THREADS), 0, st, (const double *)d_in, ld_in, d_idx,
+                       nsel, d_out, ld_out);
   return launch_ok();
 }
