@@ -236,6 +236,20 @@ int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n, const doub
                 size_t work_bytes, void *stream);
 
 /*
+ * K5x: plsr_latent with X read as pre-transposed B fragments (n <= 128).  d_XT is X^T, voxel-major
+ * with rows padded to 128 doubles and voxels padded with zero rows to whole 32-voxel tiles
+ * (plsr_latent_xt_bytes), made once per X by plsr_latent_xt_prepare.  Every wave loads its own B
+ * fragments (four voxels x its sixteen data rows = four 128-byte segments) straight into
+ * registers a tile ahead; only VS^T goes through LDS (double-buffered, one barrier per tile).
+ * Same outputs and the same limits on k as plsr_latent.
+ */
+size_t plsr_latent_xt_bytes(int32_t n, int64_t p);
+int plsr_latent_xt_prepare(const double *d_X, int64_t ldx, int64_t p, int32_t n, double *d_XT, void *stream);
+size_t plsr_latent_xt_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p);
+int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const double *d_vst, int64_t ldv, int32_t items,
+                   int32_t k, double *d_Zt, double *d_nsq, void *d_work, size_t work_bytes, void *stream);
+
+/*
  * ---- K0: a handful of operator rows applied to X ------------------------------
  * d_out (m x p, row stride ldo) = d_rows (m x n, row-major) @ X.  The observed
  * blocks of a PLS() call: _mean_centre / cell means as the operator W

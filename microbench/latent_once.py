@@ -13,6 +13,8 @@ work = torch.empty(need, dtype=torch.uint8, device=eng.device)
 Zt = torch.empty((items, k, n), dtype=torch.float64, device=eng.device)
 nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device)
 def run():
+    if "xt" in sys.argv:
+        eng.latent_batch(vst, n, Zt, nsq); return
     _lib.check(eng.lib.plsr_latent(_ptr(eng.X), eng.X.stride(0), p, n, _ptr(vst), p, items, k, _ptr(Zt), _ptr(nsq) if "nonsq" not in sys.argv else _ptr(None),
                                    _ptr(work), need, _stream()), "plsr_latent")
 for _ in range(3):

@@ -67,6 +67,10 @@ SIGNATURES = {
     "plsr_mask_indices_workspace_bytes": (c_sz, [c_i64]),
     "plsr_mask_indices": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_mask_apply_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "plsr_latent_xt_bytes": (c_sz, [c_i32, c_i64]),
+    "plsr_latent_xt_prepare": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    "plsr_latent_xt_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
+    "plsr_latent_xt": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_rng_permutation": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "plsr_rng_task_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "plsr_rng_bootstraps": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -207,4 +207,187 @@ inline size_t latent_lds_bytes(int mc, int ni, int ig, int wv) {
   return ((size_t)ig * mc * 16 + (size_t)wv * ni * 16) * LV_LD * sizeof(double);
 }
 
+// ---------------------------------------------------------------------------
+// K5x: the same product with X read as pre-transposed B fragments (n <= 128).
+//
+// K5 stages two operands per 32-voxel tile through LDS (the X tile, 128 x 32, is three quarters of
+// the bytes) and meets at two barriers per tile.  X^T (voxel-major, rows padded to 128, voxels
+// padded with zero rows to whole tiles) is laid out so that the B operand of a k-step -- four voxels
+// x the wave's sixteen data rows -- is four contiguous 128-byte segments: every wave loads its own B
+// fragments straight into registers, a whole tile ahead, and only VS^T (48 x 32 per tile, shared by
+// the waves) goes through LDS, double-buffered, with ONE barrier per tile.  Voxels past p meet zero
+// rows of X^T, so the VS^T loads are merely clamped to valid addresses, never zeroed.
+// ---------------------------------------------------------------------------
+constexpr int XT_LD = 128;     // doubles per voxel row of X^T
+
+__global__ __launch_bounds__(256) void xt_prepare_kernel(const double *X, int64_t ldx, int64_t p, int n, double *XT,
+                                                        int64_t p_pad) {
+  __shared__ double tile[32][33];
+  const int64_t v0 = (int64_t)blockIdx.x * 32;
+  const int i0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r;
+    const int64_t v = v0 + tx;
+    tile[r][tx] = (i < n && v < p) ? X[(int64_t)i * ldx + v] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t v = v0 + r;
+    if (v < p_pad) XT[v * XT_LD + i0 + tx] = tile[tx][r];
+  }
+}
+
+struct LatentXtArgs {
+  const double *XT;       // [p_pad][128]
+  int64_t p;
+  int32_t n, k, items;
+  const double *vst;      // [items][k][ldv]
+  int64_t ldv;
+  int32_t tiles_per_chunk;
+  double *Zt_part;        // [nchunk][items][k][n]
+  double *nsq_part;       // [nchunk][items][k] or null
+};
+
+template <int MC, int WV>
+__global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int NS = LV_T / 4;                    // k-steps per tile
+  constexpr int RPP = WV * 4;                     // VS^T rows staged per pass (sixteen threads per row)
+  constexpr int NV = (MC * 16 + RPP - 1) / RPP;
+  extern __shared__ __attribute__((aligned(16))) double smem[];   // two VS^T tiles [MC*16][LV_LD]
+  const bool want_nsq = A.nsq_part != nullptr;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int item = blockIdx.x;
+  const int chunk = blockIdx.y;
+  const int64_t nvt = (A.p + LV_T - 1) / LV_T;
+  const int64_t t_lo = (int64_t)chunk * A.tiles_per_chunk;
+  const int64_t t_hi = min(nvt, t_lo + A.tiles_per_chunk);
+  const int srow = tid >> 4, svox = (tid & 15) * 2;
+  constexpr int VT = MC * 16 * LV_LD;             // doubles per VS^T tile
+
+  f64x4 acc[MC];
+  double nsq[MC];
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc) {
+    acc[mc] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    nsq[mc] = 0.0;
+  }
+
+  uint32_t offv[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+    offv[q] = (uint32_t)((((int64_t)min(q * RPP + srow, min(MC * 16, (int)A.k) - 1)) * A.ldv + svox) * 8);
+  const char *vbase = (const char *)(A.vst + (int64_t)item * A.k * A.ldv);
+  // this lane's element of a B fragment: voxel 4 s + g of the tile, data row 16 wave + col
+  const double *xb = A.XT + (int64_t)g * XT_LD + 16 * wave + col;
+
+  d2 pv[NV];
+  auto fetch_v = [&](int64_t vt) {
+    const int64_t vtc = min(vt, nvt - 1);                        // (a prefetch past the end re-reads the last tile)
+    if ((vtc + 1) * LV_T <= A.p) {
+      const char *bv = vbase + vtc * (LV_T * 8);
+#pragma unroll
+      for (int q = 0; q < NV; ++q) pv[q] = *(const d2 *)(bv + offv[q]);
+    } else {
+      const int64_t v0 = vtc * LV_T + svox;
+      const int64_t c0 = (min(v0, A.p - 1) - svox) * 8, c1 = (min(v0 + 1, A.p - 1) - svox) * 8;
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+        pv[q] = (d2){*(const double *)(vbase + offv[q] + c0), *(const double *)(vbase + offv[q] + c1)};
+    }
+  };
+  auto park_v = [&](double *Vs) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int rr = q * RPP + srow;
+      if (rr < MC * 16) {
+        Vs[rr * LV_LD + svox] = pv[q].x;
+        Vs[rr * LV_LD + svox + 1] = pv[q].y;
+      }
+    }
+  };
+  // B fragments of a tile: slot s is refilled with the NEXT tile's k-step s right after its use
+  // (a whole tile of prefetch distance in eight registers)
+  double bx[NS];
+
+  if (t_lo < t_hi) {
+    fetch_v(t_lo);
+    {
+      const double *src = xb + t_lo * (LV_T * XT_LD);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bx[s] = src[(int64_t)s * 4 * XT_LD];
+    }
+    park_v(smem);
+    __syncthreads();
+    int par = 0;
+    for (int64_t vt = t_lo; vt < t_hi; ++vt) {
+      const double *Vs = smem + par * VT;
+      const double *xn = xb + min(vt + 1, nvt - 1) * (LV_T * XT_LD);   // (past the end: re-reads the last tile)
+      const bool edge = (vt + 1) * LV_T > A.p;                          // (uniform) the tile holds voxels past p
+      fetch_v(vt + 1);
+      double a0[MC], a1[MC];
+      auto lda = [&](int s, double (&a)[MC]) {
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) a[mc] = Vs[(mc * 16 + col) * LV_LD + 4 * s + g];
+      };
+      auto mm = [&](int s, double (&a)[MC]) {
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) {
+          // column norms: k-step s is wave (s mod WV)'s share; voxels past p are clamped copies and do not count
+          if (want_nsq && s % WV == wave && (!edge || vt * LV_T + 4 * s + g < A.p)) nsq[mc] = fma(a[mc], a[mc], nsq[mc]);
+          acc[mc] = mfma_f64(a[mc], bx[s], acc[mc]);
+        }
+        bx[s] = xn[(int64_t)s * 4 * XT_LD];
+      };
+      lda(0, a0);
+#pragma unroll
+      for (int s = 0; s < NS; s += 2) {
+        lda(s + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(s, a0);
+        if (s + 2 < NS) lda(s + 2, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(s + 1, a1);
+      }
+      park_v(smem + (par ^ 1) * VT);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      par ^= 1;
+    }
+  }
+
+  // Zt[j = 16 mc + g + 4 r][i = 16 wave + col]
+  double *zo = A.Zt_part + ((int64_t)chunk * A.items + item) * A.k * A.n;
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = mc * 16 + g + 4 * r;
+      const int i = wave * 16 + col;
+      if (j < A.k && i < A.n) zo[(int64_t)j * A.n + i] = acc[mc][r];
+    }
+  if (want_nsq) {
+    // the waves' shares of the column norms, summed through LDS
+    __syncthreads();
+    double *red = smem;                            // [WV][MC*16]
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
+      double x = nsq[mc];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      if (g == 0) red[wave * (MC * 16) + mc * 16 + col] = x;
+    }
+    __syncthreads();
+    if (tid < MC * 16 && tid < A.k) {
+      double x = 0.0;
+      for (int w = 0; w < WV; ++w) x += red[w * (MC * 16) + tid];
+      A.nsq_part[((int64_t)chunk * A.items + item) * A.k + tid] = x;
+    }
+  }
+}
+
 }  // namespace plsr

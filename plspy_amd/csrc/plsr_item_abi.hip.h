@@ -150,6 +150,91 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
   return launch_ok();
 }
 
+// ---- K5x: X read as pre-transposed B fragments (n <= 128) ----
+extern "C" size_t plsr_latent_xt_bytes(int32_t n, int64_t p) {
+  if (n <= 0 || n > XT_LD || p <= 0) return 0;
+  return (size_t)((p + LV_T - 1) / LV_T * LV_T) * XT_LD * sizeof(double);
+}
+
+extern "C" int plsr_latent_xt_prepare(const double *d_X, int64_t ldx, int64_t p, int32_t n, double *d_XT, void *stream) {
+  if (!d_X || !d_XT || n <= 0 || n > XT_LD || p <= 0 || ldx < p) return PLSR_EINVAL;
+  const int64_t p_pad = (p + LV_T - 1) / LV_T * LV_T;
+  hipLaunchKernelGGL(xt_prepare_kernel, dim3((unsigned)(p_pad / 32), XT_LD / 32), dim3(256), 0, (hipStream_t)stream, d_X,
+                     ldx, p, n, d_XT, p_pad);
+  return launch_ok();
+}
+
+extern "C" int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const double *d_vst, int64_t ldv,
+                              int32_t items, int32_t k, double *d_Zt, double *d_nsq, void *d_work, size_t work_bytes,
+                              void *stream) {
+  if (!d_XT || !d_vst || !d_Zt || !d_work || ldv < p) return PLSR_EINVAL;
+  if (n <= 0 || n > XT_LD || k <= 0 || k > 64) return PLSR_EUNSUPPORTED;
+  LatentPlan pl;
+  if (!latent_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
+  // one item per workgroup here: chunks for `items` groups
+  {
+    const int64_t nvt = (p + LV_T - 1) / LV_T;
+    const int lo = (int)std::max<int64_t>(1, (768 + items - 1) / items);
+    const int hi = (int)std::max<int64_t>(lo, (2048 + items - 1) / items);
+    int want = lo;
+    double best = -1.0;
+    for (int c = lo; c <= hi; ++c) {
+      const double rounds = (double)items * c / 512.0;
+      const double eff = rounds / std::ceil(rounds);
+      if (eff > best + 1e-3) {
+        best = eff;
+        want = c;
+      }
+    }
+    want = (int)std::min<int64_t>(want, nvt);
+    pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
+    pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
+    pl.z_elems = (size_t)pl.nchunk * items * k * n;
+    pl.n_elems = (size_t)pl.nchunk * items * k;
+    pl.bytes = ((pl.z_elems + pl.n_elems) * sizeof(double) + 511) / 256 * 256;
+  }
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  if ((int64_t)k * ldv * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;
+  LatentXtArgs a;
+  a.XT = d_XT;
+  a.p = p;
+  a.n = n;
+  a.k = k;
+  a.items = items;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  a.tiles_per_chunk = pl.tiles_per_chunk;
+  a.Zt_part = (double *)d_work;
+  a.nsq_part = d_nsq ? a.Zt_part + pl.z_elems : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int MC = (k + 15) / 16, WV = (n + 15) / 16;
+  const size_t lds = std::max((size_t)2 * MC * 16 * LV_LD, (size_t)8 * MC * 16) * sizeof(double);
+  int rc = PLSR_EUNSUPPORTED;
+#define PLSR_LX(M, W)                                                                                              \
+  if (MC == M && WV <= W && rc == PLSR_EUNSUPPORTED) {                                                             \
+    hipLaunchKernelGGL((latent_xt_kernel<M, W>), dim3((unsigned)items, (unsigned)pl.nchunk), dim3(W * 64), lds, st, \
+                       a);                                                                                         \
+    rc = launch_ok();                                                                                              \
+  }
+  PLSR_LX(1, 4) PLSR_LX(1, 8) PLSR_LX(2, 4) PLSR_LX(2, 8) PLSR_LX(3, 4) PLSR_LX(3, 8) PLSR_LX(4, 4) PLSR_LX(4, 8)
+#undef PLSR_LX
+  if (rc) return rc;
+  const int64_t EZ = (int64_t)items * k * n, EN = (int64_t)items * k;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EZ + 255) / 256), 1), dim3(256), 0, st,
+                     (const double *)a.Zt_part, d_Zt, EZ, pl.nchunk, pl.nchunk);
+  if (d_nsq)
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
+                       (const double *)a.nsq_part, d_nsq, EN, pl.nchunk, pl.nchunk);
+  return launch_ok();
+}
+
+extern "C" size_t plsr_latent_xt_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p) {
+  if (n <= 0 || n > XT_LD || k <= 0 || k > 64 || items <= 0 || p <= 0) return 0;
+  const int64_t nvt = (p + LV_T - 1) / LV_T;
+  const int64_t hi = std::min<int64_t>(nvt, std::max<int64_t>(1, (2048 + items - 1) / items));
+  return (size_t)(((size_t)hi * items * k * (n + 1)) * sizeof(double) + 511) / 256 * 256;
+}
+
 // ---------------------------------------------------------------------------
 // K4f: fused gather / z-score / projection (plsr_fused.hip.h)
 // ---------------------------------------------------------------------------

@@ -81,6 +81,8 @@ class ProjectionEngine:
         self.work_limit = int(work_limit) if work_limit is not None else DEFAULT_WORK_LIMIT
         self._lanes = {}
         self._pool = {}
+        self._XT = None
+        self._XT_n = 0
         self._tail = None
         self._h2d = None
         self._d2h = None
@@ -287,6 +289,30 @@ class ProjectionEngine:
         _lib.check(self.lib.plsr_apply_rows(_ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_rows), m,
                                             _ptr(out), self.p, _stream()), "plsr_apply_rows")
         return out
+
+    def latent_batch(self, vst, n, Zt, nsq=None):
+        """K5 / K5x for a batch: Zt (cnt, k, n) <- VS_b X[:n]^T from vst (cnt, k, p), nsq (cnt, k) the
+        squared column norms (optional).  With at most 128 data rows X is read as pre-transposed B
+        fragments (made once per engine); otherwise through the LDS-staged kernel."""
+        cnt, k = int(vst.shape[0]), int(vst.shape[1])
+        if n <= 128 and k <= 64 and os.environ.get("PLSR_LATENT_XT", "1") != "0":
+            if self._XT is None or self._XT_n != n:
+                nb = self.lib.plsr_latent_xt_bytes(n, self.p)
+                self._XT = torch.empty(nb // 8, dtype=torch.float64, device=self.device)
+                _lib.check(self.lib.plsr_latent_xt_prepare(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(self._XT),
+                                                           _stream()), "plsr_latent_xt_prepare")
+                self._XT_n = n
+            need = self.lib.plsr_latent_xt_workspace_bytes(n, k, cnt, self.p)
+            work = self._buf("k5work", need)
+            _lib.check(self.lib.plsr_latent_xt(_ptr(self._XT), self.p, n, _ptr(vst), vst.stride(1), cnt, k, _ptr(Zt),
+                                               _ptr(nsq), _ptr(work), need, _stream()), "plsr_latent_xt")
+            return
+        need = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
+        if need == 0:
+            raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
+        work = self._buf("k5work", need)
+        _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), vst.stride(1), cnt, k,
+                                        _ptr(Zt), _ptr(nsq), _ptr(work), need, _stream()), "plsr_latent")
 
     def latents_device(self, vt):
         """(1, k, n) device tensor (X @ V)^T for V^T = vt (k, p) on the device (K5, one item)."""
@@ -616,13 +642,7 @@ class ProjectionEngine:
                                            src_ranges=ranges if use_agg else None, pool=True)
             if not use_agg:
                 nsq[lo:hi] = rsq
-            need2 = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
-            if need2 == 0:
-                raise _lib.PlsrError(f"plsr_latent: unsupported shape n={n} k={k}")
-            work2 = self._buf("k5work", need2)
-            _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), self.p, cnt,
-                                            k, _ptr(Zt[lo:hi]), _ptr(nsq[lo:hi]) if use_agg else _ptr(None),
-                                            _ptr(work2), need2, _stream()), "plsr_latent")
+            self.latent_batch(vst, n, Zt[lo:hi], nsq[lo:hi] if use_agg else None)
             if on_batch is not None:
                 ev = torch.cuda.Event()
                 ev.record()

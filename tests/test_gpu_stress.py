@@ -259,6 +259,28 @@ def test_fused_gram_and_latent_random_shapes():
         np.testing.assert_allclose(nsq.cpu().numpy(), (vs ** 2).sum(-1), rtol=1e-10, err_msg=tag)
 
 
+def test_latent_batch_random_shapes():
+    """engine.latent_batch against NumPy: K5x (X read as pre-transposed B fragments, n <= 128) and the
+    LDS-staged K5 beyond; voxel counts off the 32-voxel tile, k off the 16-row tile, 4- and 8-wave shapes."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(41)
+    for n, p, k, items in [(5, 1, 1, 1), (60, 257, 6, 3), (64, 1000, 17, 2), (65, 333, 48, 5), (120, 2001, 38, 4),
+                           (128, 96, 64, 2), (17, 31, 33, 7), (130, 515, 12, 3), (200, 64, 48, 2)]:
+        X = rs.randn(n, p) + 2.0
+        vs = rs.randn(items, k, p)
+        eng = ProjectionEngine(X)
+        Zt = torch.empty((items, k, n), dtype=torch.float64, device=eng.device)
+        nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device)
+        eng.latent_batch(eng.dev(vs), n, Zt, nsq)
+        want = np.einsum("bjv,iv->bji", vs, X)
+        tag = f"n={n} p={p} k={k} items={items}"
+        np.testing.assert_allclose(Zt.cpu().numpy(), want, rtol=1e-11, atol=1e-11 * np.abs(want).max(), err_msg=tag)
+        np.testing.assert_allclose(nsq.cpu().numpy(), (vs ** 2).sum(-1), rtol=1e-11, err_msg=tag)
+        eng.latent_batch(eng.dev(vs), n, Zt)                       # without the norms
+        np.testing.assert_allclose(Zt.cpu().numpy(), want, rtol=1e-11, atol=1e-11 * np.abs(want).max(), err_msg=tag)
+
+
 def test_projection_phases_random_shapes():
     """K1 through the engine: permutation norms, bootstrap moments / norms / T and
     the dumped VS for random n, k (all periods incl. padded ones), R, p."""
