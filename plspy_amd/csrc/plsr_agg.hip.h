@@ -392,7 +392,7 @@ __global__ __launch_bounds__(AG_WAVES * 64, 2) void item_agg_kernel(AggArgs A) {
     if (jl + jrow < A.k) {
       char *dst = (char *)hold_base + (int64_t)jrow * A.ldv * 8 + loff;
       if (vcode == 2) {
-        *(d2 *)dst = pc;
+        __builtin_nontemporal_store(pc, (d2 *)dst);            // streamed: K5 reads it back from HBM anyway
       } else if (vcode == 1) {
         *(double *)dst = pc.x;
       }

@@ -127,6 +127,9 @@ struct BehArgs {
   double *S1, *S2;                     // [split][p][k] plain partial sums (overwritten), or null
   double *vst;                         // [items][k][ldv] or null
   int64_t ldv;
+#ifdef BEH_TIMING
+  long long *dbg;                      // developer-only: [workgroup][wave][8] cycle counts
+#endif
 };
 
 template <int CSMAX, int NCMAX, int BP>
@@ -196,13 +199,22 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
   auto stats_group = [&](int sg) {
     const double *mp = A.mfrag + ((size_t)sg * ncell * cs) * 64 + lane;
     uint32_t susp = 0;
+    // the multiplicity fragments of cell c + 1 are fetched while cell c is summed (an L2 round trip
+    // per cell was the larger part of this phase)
+    double mfn[CSMAX];
+#pragma unroll
+    for (int t = 0; t < CSMAX; ++t) mfn[t] = mp[(size_t)(t < cs ? t : 0) * 64];
 #pragma unroll
     for (int c = 0; c < NCMAX; ++c) {
       if (c < ncell) {
         double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0;
         double mf[CSMAX];
 #pragma unroll
-        for (int t = 0; t < CSMAX; ++t) mf[t] = mp[(size_t)(t < cs ? t : 0) * 64];
+        for (int t = 0; t < CSMAX; ++t) mf[t] = mfn[t];
+        if (c + 1 < ncell) {
+#pragma unroll
+          for (int t = 0; t < CSMAX; ++t) mfn[t] = mp[(size_t)(cs + (t < cs ? t : 0)) * 64];
+        }
 #pragma unroll
         for (int t = 0; t < CSMAX; ++t) {
           if (t < cs) {
@@ -288,8 +300,18 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
   const int vcode = (v - odd) + 1 < A.p ? 2 : ((v - odd) < A.p ? 1 : 0);
 
   int par = 0;
+#ifdef BEH_TIMING
+  long long t_stats = 0, t_mm = 0, t_bar = 0, t_epi = 0;
+  const long long t_begin = clock64();
+#define BEH_T(var, t0) var += clock64() - t0
+#else
+#define BEH_T(var, t0)
+#endif
   stats_group(it_lo >> 2);
   for (int item0 = it_lo; item0 < it_hi; item0 += IP) {
+#ifdef BEH_TIMING
+    const long long tm0 = clock64();
+#endif
     const double *cur = bufs + par * unit_p + lane;
     d2 *nxt = (d2 *)(bufs + (par ^ 1) * unit_p) + tid;
     gsrc += unit / 2;                              // next group's pieces (the stream is padded by one unit)
@@ -308,48 +330,64 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
     const double *a1p = cur;
     const double *u2p = u2s + lane;
     const double *stl = st + ((item0 - it_lo) & 3) * 16 + col;    // scale of item ii: + ii * 16
-    // cells: stage 1 of cell c is issued before the scaling / stage 2 of cell c - 1 (two stage-1
-    // accumulators in turn), so that the VALU scaling never waits for the MFMA it has just issued
-    f64x4 acc1[2];
-    auto stage2 = [&](int c, f64x4 &r1) {
-      double scl[IP];
+    // Operands are fetched in batches AHEAD of the branches that guard the MFMAs (the step counts are
+    // run-time values): left inside them, every MFMA sat behind its own ds_read + s_waitcnt.  The
+    // stage-1 fragments of cell c + 1 and the U fragments / scales of cell c are in flight while cell
+    // c's stage-1 MFMAs run; loads past a cell's last k-step re-read its first (value unused).
+    double fan[CSMAX];
 #pragma unroll
-      for (int ii = 0; ii < IP; ++ii) scl[ii] = stl[c * 64 + ii * 16];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ii = (4 * r) / BP, qq = ((4 * r) % BP) / 4;
-        const double bop = r1[r] * scl[ii];
-#pragma unroll
-        for (int mc = 0; mc < MCM; ++mc)
-          if (mc < MC) acc2[ii][mc] = mfma_f64(u2p[((size_t)(c * QB + qq) * MC + mc) * 64], bop, acc2[ii][mc]);
-      }
-    };
+    for (int t = 0; t < CSMAX; ++t) fan[t] = a1p[(size_t)(t < cs ? t : 0) * 64];
 #pragma unroll
     for (int c = 0; c < NCMAX; ++c) {
       if (c < ncell) {
+        a1p += (size_t)cs * 64;                                  // -> the next cell's fragments
+        // this cell's U fragments and scales: in flight during its stage-1 MFMAs
+        double uf[QB][MCM], scl[IP];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+          for (int mc = 0; mc < MCM; ++mc) uf[qq][mc] = u2p[((size_t)(c * QB + qq) * MC + (mc < MC ? mc : 0)) * 64];
+#pragma unroll
+        for (int ii = 0; ii < IP; ++ii) scl[ii] = stl[c * 64 + ii * 16];
         f64x4 r1 = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < CSMAX; ++t)
-          if (t < cs) r1 = mfma_f64(a1p[(size_t)t * 64], x[c * CSMAX + t], r1);
-        a1p += (size_t)cs * 64;
-        acc1[c & 1] = r1;
-        if (c > 0) stage2(c - 1, acc1[(c - 1) & 1]);
+        for (int t = 0; t < CSMAX; ++t) {
+          if (t < cs) r1 = mfma_f64(fan[t], x[c * CSMAX + t], r1);
+          fan[t] = a1p[(size_t)(t < cs ? t : 0) * 64];           // slot t: refilled right after its use (past the last cell: unused)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ii = (4 * r) / BP, qq = ((4 * r) % BP) / 4;
+          const double bop = r1[r] * scl[ii];
+#pragma unroll
+          for (int mc = 0; mc < MCM; ++mc)
+            if (mc < MC) acc2[ii][mc] = mfma_f64(uf[qq][mc], bop, acc2[ii][mc]);
+        }
       }
     }
-#pragma unroll
-    for (int c = 0; c < NCMAX; ++c)
-      if (c == ncell - 1) stage2(c, acc1[c & 1]);
 
     // The scales of the NEXT four items are computed here, ahead of this group's stores: a wave's
     // memory operations retire in order, and the multiplicity loads of the statistics, issued right
     // behind an item's 12 KB of stores, waited until HBM had taken them (a quarter of the kernel).
+#ifdef BEH_TIMING
+    const long long ts0 = clock64();
+    t_mm += ts0 - tm0;
+#endif
     if (((item0 + IP - it_lo) & 3) == 0 && item0 + IP < it_hi) stats_group((item0 + IP) >> 2);
+#ifdef BEH_TIMING
+    const long long tb0 = clock64();
+    t_stats += tb0 - ts0;
+#endif
     // the next group's fragments into the other buffer; everybody is done reading this one
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (q < npc) nxt[q * (BH_WAVES * 64)] = park[q];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     par ^= 1;
+#ifdef BEH_TIMING
+    const long long te0 = clock64();
+    t_bar += te0 - tb0;
+#endif
 
     // ---- group done: acc2[ii][mc][r] = VS of item item0 + ii, rows 16 mc + g + 4 r, voxel col ----
 #pragma unroll
@@ -377,7 +415,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
                 if (jl + jrow < A.k) {
                   char *dst = (char *)base + (int64_t)jrow * A.ldv * 8 + loff;
                   if (vcode == 2) {
-                    *(d2 *)dst = pc;
+                    __builtin_nontemporal_store(pc, (d2 *)dst);        // streamed: K5 reads it back from HBM anyway
                   } else if (vcode == 1) {
                     *(double *)dst = pc.x;
                   }
@@ -388,8 +426,22 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
         }
       }
     }
+#ifdef BEH_TIMING
+    t_epi += clock64() - te0;
+#endif
   }
 
+#ifdef BEH_TIMING
+  if (lane == 0 && A.dbg != nullptr) {
+    long long *o = A.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BH_WAVES + wave) * 8;
+    o[0] = clock64() - t_begin;
+    o[1] = t_stats;
+    o[2] = t_mm;
+    o[3] = t_bar;
+    o[4] = t_epi;
+    o[5] = it_hi - it_lo;
+  }
+#endif
   if (moments) {
     double *o1 = A.S1 + (int64_t)blockIdx.y * A.p * A.k;
     double *o2 = A.S2 + (int64_t)blockIdx.y * A.p * A.k;

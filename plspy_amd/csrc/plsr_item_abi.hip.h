@@ -1019,12 +1019,34 @@ extern "C" int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t 
   a.S2 = d_S1 ? a.S1 + (size_t)pl.nsplit * p * k : nullptr;
   a.vst = d_vst;
   a.ldv = ldv;
+#ifdef BEH_TIMING
+  static long long *bdbg = nullptr;
+  const size_t nbdbg = (size_t)pl.nwg * pl.nsplit * BH_WAVES * 8;
+  if (!bdbg) (void)hipMalloc(&bdbg, 64 << 20);
+  (void)hipMemsetAsync(bdbg, 0, nbdbg * 8, st);
+  a.dbg = bdbg;
+#endif
   int rc = PLSR_EUNSUPPORTED;
   if (pl.CSMAX == 5) rc = run_beh<5, 6>(a, pl, st);
   if (pl.CSMAX == 8) rc = run_beh<8, 4>(a, pl, st);
   if (pl.CSMAX == 4) rc = run_beh<4, 8>(a, pl, st);
   if (pl.CSMAX == 2) rc = run_beh<2, 16>(a, pl, st);
   if (rc) return rc;
+#ifdef BEH_TIMING
+  {
+    std::vector<long long> h(nbdbg);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), bdbg, nbdbg * 8, hipMemcpyDeviceToHost);
+    double sum[5] = {0, 0, 0, 0, 0};
+    long long n_it = 0;
+    for (size_t i = 0; i < nbdbg / 8; ++i) {
+      for (int q = 0; q < 5; ++q) sum[q] += (double)h[i * 8 + q];
+      n_it += h[i * 8 + 5];
+    }
+    fprintf(stderr, "[beh timing] ticks per wave-item: total %.0f stats %.0f stage1+2 %.0f write+barrier %.0f epilogue %.0f\n",
+            sum[0] / n_it, sum[1] / n_it, sum[2] / n_it, sum[3] / n_it, sum[4] / n_it);
+  }
+#endif
   if (d_S1) {
     const int64_t cnt = p * k;
     hipLaunchKernelGGL(moment_unshift_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_S1, d_S2,
