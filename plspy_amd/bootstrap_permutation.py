@@ -497,6 +497,15 @@ class _ResampleTestPLS(ResampleTest):
         with np.errstate(divide="ignore", invalid="ignore"):
             return np.where(norms[:, None, :] != 0, Z / norms[:, None, :], 0.0)
 
+    def _finalize_early(self, niter, ref):
+        """boot_items callback (single rank): std_errs / boot_ratios and their download, enqueued behind
+        the last batch so that they overlap the host's consumption of the pending batches."""
+        _, nranks = dist.world()
+        if nranks > 1:
+            return None
+        eng = self._engine
+        return lambda S1, S2: eng.fetch_async(list(eng.boot_finalize(S1, S2, niter, num=ref)))
+
     def _finish_items(self, res, per_resample, niter, ref):
         """Exchange a sharded boot_items result (moment sums, and the per-resample
         summaries the host formed batch by batch) and form std_errs / boot_ratios."""
@@ -508,6 +517,9 @@ class _ResampleTestPLS(ResampleTest):
             S1, S2 = S12[0], S12[1]
         else:
             S1, S2 = res["S1"], res["S2"]
+        if res.get("after") is not None and nranks == 1:
+            sd_h, ratio_h = res["after"].get()                                 # enqueued behind the last batch
+            return sd_h, ratio_h, per_resample
         sd, ratio = eng.boot_finalize(S1, S2, niter, num=ref)                  # :695, :701
         sd_h, ratio_h = eng.fetch_async([sd, ratio]).get()                     # (page-locked buffers, see engine)
         return sd_h, ratio_h, per_resample
@@ -546,7 +558,8 @@ class _ResampleTestPLS(ResampleTest):
             LVc[a:z] = cf.lvcorr_from_latents(Lt, cf.zscore_cells(Y[mine[a:z]], bounds), bounds)
 
         res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch,
-                             beh=(lambda a, z: cf.zscore_cells(Y[mine[a:z]], bounds), U))
+                             beh=(lambda a, z: cf.zscore_cells(Y[mine[a:z]], bounds), U),
+                             after_enqueue=self._finalize_early(niter, ref))
         std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z                                      # :723-724
@@ -624,7 +637,7 @@ class _ResampleTestPLS(ResampleTest):
                 Td[a:z] = cf.cell_means_rows(Zn, co)
 
         res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n,
-                             on_batch=on_batch, project_on=U)
+                             on_batch=on_batch, project_on=U, after_enqueue=self._finalize_early(niter, ref))
         std_errs, boot_ratios, (LVcorr, Tdistrib) = self._finish_items(res, [LVc, Td], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = np.std(LVcorr, axis=0) * z

@@ -546,8 +546,26 @@ class ProjectionEngine:
             "plsr_item_beh")
         return vst
 
+    @staticmethod
+    def _batch_bounds(R, step):
+        """Batches of `step` resamples with a short first and a short last one: the device starts
+        after a quarter batch's worth of host preparation, and what stays exposed at the end -- the
+        last batch's device time and its host post-processing -- is a quarter batch, too."""
+        q = max(4, step // 4 // 4 * 4)
+        if R <= 2 * step or q >= step:
+            return [(lo, min(R, lo + step)) for lo in range(0, R, step)]
+        out, lo = [(0, q)], q
+        while R - lo > step + q:
+            out.append((lo, lo + step))
+            lo += step
+        if R - lo > q:
+            out.append((lo, R - q))
+            lo = R - q
+        out.append((lo, R))
+        return out
+
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
-                   on_batch=None, project_on=None, beh=None):
+                   on_batch=None, project_on=None, beh=None, after_enqueue=None):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -600,8 +618,7 @@ class ProjectionEngine:
         # the cells of a bootstrap sample read fixed ranges of source rows: aggregated-operator
         # kernel (K4a) when the shape allows; it leaves the column norms to the latent kernel
         ranges = self.source_ranges(src, cell_lo)
-        for lo in range(0, R, step):
-            hi = min(R, lo + step)
+        for lo, hi in self._batch_bounds(R, step):
             cnt = hi - lo
             d_src = self.dev(src[lo:hi], torch.int32)
             use_agg = self._agg_bytes(nz, k, cell_lo, cell_z, ranges, cnt, True, False) > 0
@@ -654,9 +671,12 @@ class ProjectionEngine:
                 # instead of 6 (the "sporadic slow launch" of the kernel trace).
                 while len(pending) > 2:
                     deliver(pending.pop(0))
+        # whatever only needs the moment sums (std_errs / boot_ratios and their download) is enqueued
+        # now, behind the last batch, and proceeds while the host consumes the batches still pending
+        after = after_enqueue(S1, S2) if after_enqueue is not None else None
         while pending:
             deliver(pending.pop(0))
-        return {"S1": S1, "S2": S2, "S12": S12, "Zt": Zt, "nsq": nsq, "R": R}
+        return {"S1": S1, "S2": S2, "S12": S12, "Zt": Zt, "nsq": nsq, "R": R, "after": after}
 
     def eigh(self, G, off, k, init=None, relative=False):
         """Eigen-decomposition of the k x k diagonal block at `off` of every
