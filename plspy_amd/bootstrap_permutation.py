@@ -22,8 +22,9 @@ Random draws replicate the reference's np.random call order (resample.py).
 Coverage: permutation and bootstrap tests for mct, rb, mb and the contrast
 variants cst / csb / cmb (projection on the normalised contrast matrix instead of
 the observed U, :429-433, :658-675).  In the rb / mb bootstrap every resample
-z-scores its own resampled rows, so each resample is an item of the fused item
-kernels (K4f / K5).  The csb bootstrap ends in the reference's own ValueError
+z-scores its own resampled rows, so each resample is an item of the item kernels
+(rb: K4b, the two-stage kernel; mb / cmb: K4a, aggregated operators; K4f for
+shapes those do not serve; then K5x / K5 for the latent scores).  The csb bootstrap ends in the reference's own ValueError
 (pls_classes.py:1158 hands a q x q matrix to :725).  Nothing falls back to a CPU
 path."""
 import abc

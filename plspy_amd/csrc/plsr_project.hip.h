@@ -512,7 +512,12 @@ __global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) 
 //     accumulator registers directly as the B operand of v_mfma_f64_4x4x4_4b
 //     (B_b[k][j]: k = voxel, j = batch column) -- no LDS transpose anywhere.
 // Moments are plain sums (zero-padded columns contribute nothing); the shift by
-// the observed VS is applied at the merge (moment_unshift_kernel).
+// the observed VS is applied at the merge (moment_shift_merge_kernel).  Precision: expanding
+// sum (x - ref)^2 = sum x^2 - 2 ref sum x + R ref^2 cancels (ref / sd)^2 -- the squared bootstrap
+// ratio of the voxel -- of the 2^53: a voxel with |boot ratio| = 30 keeps 1e-13 relative accuracy in
+// std_errs (the parity tolerance is 1e-9); the LDS-fed kernel and K4a / K4b's merge do the same or
+// accumulate about ref directly.  A voxel whose bootstrap values are constant to 1e-8 of their size
+// would lose everything -- so would the reference's np.std within a few digits.
 // LDS (per wave = per workgroup): the 64 voxels of the cell means [4 nh][XM_LD] and the
 // second-moment accumulators [16][64] (lane-private slots; in registers they
 // pushed the nk >= 12 instances into scratch).
