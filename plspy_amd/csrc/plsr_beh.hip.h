@@ -160,6 +160,10 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
   double *u2s = smem;
   double *bufs = smem + (size_t)ncell * QB * MC * 64;
   double *st = bufs + 2 * unit_p + (size_t)wave * ncell * 64;    // [cell][item-in-four * 16 + voxel] scale
+  // rows of the cells and their reciprocals: from LDS, not from the kernel arguments (sixteen cells'
+  // worth of them held in SGPRs pushed the wide layouts into scratch)
+  double *ctab = bufs + 2 * unit_p + (size_t)BH_WAVES * ncell * 64;
+  if (tid < 2 * AG_MAXZC) ctab[tid] = (tid & 1) ? A.rcnt[tid >> 1] : A.cnt[tid >> 1];
 
   // ---- X in registers, cell by cell, centred by the voxel's grand mean over all n rows ----
   double x[NF];
@@ -199,44 +203,41 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
   auto stats_group = [&](int sg) {
     const double *mp = A.mfrag + ((size_t)sg * ncell * cs) * 64 + lane;
     uint32_t susp = 0;
+    int ncell_ = ncell, cs_ = cs;
+    asm volatile("" : "+s"(ncell_), "+s"(cs_));          // (see the group loop)
     // the multiplicity fragments of cell c + 1 are fetched while cell c is summed (an L2 round trip
     // per cell was the larger part of this phase)
     double mfn[CSMAX];
 #pragma unroll
-    for (int t = 0; t < CSMAX; ++t) mfn[t] = mp[(size_t)(t < cs ? t : 0) * 64];
+    for (int t = 0; t < CSMAX; ++t) mfn[t] = mp[(size_t)(t < cs_ ? t : 0) * 64];
 #pragma unroll
     for (int c = 0; c < NCMAX; ++c) {
-      if (c < ncell) {
+      if (c < ncell_) {
         double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0;
-        double mf[CSMAX];
-#pragma unroll
-        for (int t = 0; t < CSMAX; ++t) mf[t] = mfn[t];
-        if (c + 1 < ncell) {
-#pragma unroll
-          for (int t = 0; t < CSMAX; ++t) mfn[t] = mp[(size_t)(cs + (t < cs ? t : 0)) * 64];
-        }
 #pragma unroll
         for (int t = 0; t < CSMAX; ++t) {
-          if (t < cs) {
+          const double m = mfn[t];
+          mfn[t] = mp[(size_t)(cs_ + (t < cs_ ? t : 0)) * 64];     // slot t: the next cell's, right after its use
+          if (t < cs_) {
             const double xv = x[c * CSMAX + t];
             if (t & 1) {
-              s1b = mfma4_f64(mf[t], xv, s1b);
-              s2b = mfma4_f64(mf[t], xv * xv, s2b);
+              s1b = mfma4_f64(m, xv, s1b);
+              s2b = mfma4_f64(m, xv * xv, s2b);
             } else {
-              s1a = mfma4_f64(mf[t], xv, s1a);
-              s2a = mfma4_f64(mf[t], xv * xv, s2a);
+              s1a = mfma4_f64(m, xv, s1a);
+              s2a = mfma4_f64(m, xv * xv, s2a);
             }
           }
         }
         const double s1c = s1a + s1b, s2c = s2a + s2b;
-        const double cnt = A.cnt[c];
-        const double mu = s1c * A.rcnt[c];
+        const double cnt = ctab[2 * c];
+        const double mu = s1c * ctab[2 * c + 1];
         const double var = fma(-s1c, mu, s2c);
         const double em = 2.220446049250313e-16 * fabs(mu + d);
         const bool dead = !(var > cnt * em * em);
         if (s2c > 0.0 && !(var > 6.1e-5 * s2c)) susp |= 1u << c;
         st[c * 64 + lane] = dead ? 0.0 : rsqrt(var);
-        mp += (size_t)cs * 64;
+        mp += (size_t)cs_ * 64;
       }
     }
     if (__builtin_amdgcn_ballot_w64(susp != 0) == 0) return;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
       if (c < ncell) {
         const uint64_t hit = __builtin_amdgcn_ballot_w64((susp >> c) & 1u);
         if (hit != 0) {
-          const double cnt = A.cnt[c];
+          const double cnt = ctab[2 * c];
           double a1 = 0.0;
 #pragma unroll
           for (int t = 0; t < CSMAX; ++t)
@@ -312,14 +313,14 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
 #ifdef BEH_TIMING
     const long long tm0 = clock64();
 #endif
+    // opaque copies of the step counts: compared inside the loop (s_cmp + s_cbranch_scc) instead of the
+    // comparisons being hoisted out of it as one 64-bit mask per guard -- two dozen SGPR pairs that
+    // spilled into VGPR lanes and from there into scratch
+    int ncell_ = ncell, cs_ = cs, MC_ = MC;
+    asm volatile("" : "+s"(ncell_), "+s"(cs_), "+s"(MC_));
     const double *cur = bufs + par * unit_p + lane;
     d2 *nxt = (d2 *)(bufs + (par ^ 1) * unit_p) + tid;
     gsrc += unit / 2;                              // next group's pieces (the stream is padded by one unit)
-    // the next group's fragments: loaded now, parked for the life of this group, written at its end
-    d2 park[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < npc) park[q] = gsrc[q * (BH_WAVES * 64)];
 
     f64x4 acc2[IP][MCM];
 #pragma unroll
@@ -336,24 +337,24 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
     // c's stage-1 MFMAs run; loads past a cell's last k-step re-read its first (value unused).
     double fan[CSMAX];
 #pragma unroll
-    for (int t = 0; t < CSMAX; ++t) fan[t] = a1p[(size_t)(t < cs ? t : 0) * 64];
+    for (int t = 0; t < CSMAX; ++t) fan[t] = a1p[(size_t)(t < cs_ ? t : 0) * 64];
 #pragma unroll
     for (int c = 0; c < NCMAX; ++c) {
-      if (c < ncell) {
-        a1p += (size_t)cs * 64;                                  // -> the next cell's fragments
+      if (c < ncell_) {
+        a1p += (size_t)cs_ * 64;                                  // -> the next cell's fragments
         // this cell's U fragments and scales: in flight during its stage-1 MFMAs
         double uf[QB][MCM], scl[IP];
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq)
 #pragma unroll
-          for (int mc = 0; mc < MCM; ++mc) uf[qq][mc] = u2p[((size_t)(c * QB + qq) * MC + (mc < MC ? mc : 0)) * 64];
+          for (int mc = 0; mc < MCM; ++mc) uf[qq][mc] = u2p[((size_t)(c * QB + qq) * MC_ + (mc < MC_ ? mc : 0)) * 64];
 #pragma unroll
         for (int ii = 0; ii < IP; ++ii) scl[ii] = stl[c * 64 + ii * 16];
         f64x4 r1 = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < CSMAX; ++t) {
-          if (t < cs) r1 = mfma_f64(fan[t], x[c * CSMAX + t], r1);
-          fan[t] = a1p[(size_t)(t < cs ? t : 0) * 64];           // slot t: refilled right after its use (past the last cell: unused)
+          if (t < cs_) r1 = mfma_f64(fan[t], x[c * CSMAX + t], r1);
+          fan[t] = a1p[(size_t)(t < cs_ ? t : 0) * 64];           // slot t: refilled right after its use (past the last cell: unused)
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
           const double bop = r1[r] * scl[ii];
 #pragma unroll
           for (int mc = 0; mc < MCM; ++mc)
-            if (mc < MC) acc2[ii][mc] = mfma_f64(uf[qq][mc], bop, acc2[ii][mc]);
+            if (mc < MC_) acc2[ii][mc] = mfma_f64(uf[qq][mc], bop, acc2[ii][mc]);
         }
       }
     }
@@ -373,7 +374,14 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
     const long long ts0 = clock64();
     t_mm += ts0 - tm0;
 #endif
+    // the next group's fragments are loaded after the statistics (the previous group's stores are a whole
+    // group old by now) and written at once: held in registers for the life of the group they pushed
+    // four of the register layouts into scratch
     if (((item0 + IP - it_lo) & 3) == 0 && item0 + IP < it_hi) stats_group((item0 + IP) >> 2);
+    d2 park[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < npc) park[q] = gsrc[q * (BH_WAVES * 64)];
 #ifdef BEH_TIMING
     const long long tb0 = clock64();
     t_stats += tb0 - ts0;

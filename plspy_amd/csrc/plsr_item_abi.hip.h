@@ -916,8 +916,8 @@ bool beh_plan(int32_t n, int32_t nz, int32_t b, int32_t k, const int32_t *cell_l
   }
   pl.per = (pl.nsg + pl.nsplit - 1) / pl.nsplit * 4;
   pl.nsplit = (items + pl.per - 1) / pl.per;
-  pl.lds = ((size_t)ncell * (pl.BP / 4) * pl.MC * 64 + (size_t)2 * pl.unit_p + (size_t)BH_WAVES * ncell * 64) *
-           sizeof(double);
+  pl.lds = ((size_t)ncell * (pl.BP / 4) * pl.MC * 64 + (size_t)2 * pl.unit_p + (size_t)BH_WAVES * ncell * 64 +
+            2 * AG_MAXZC) * sizeof(double);
   if (pl.lds > 160 * 1024) return false;
   size_t off = 0;
   auto take = [&](size_t bytes) {
