@@ -425,22 +425,30 @@ class _ResampleTestPLS(ResampleTest):
                              overlap_tail=True)
         pending = []
 
+        early = {}
+
         def tail():
             eng.join()
             per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
             per, (S12,) = dist.exchange(per, [res["S12"]], niter)
             sd, ratio = eng.boot_finalize(S12[0], S12[1], niter, num=ref)  # :695, :701
             pending.append(eng.fetch_async([sd, ratio] + list(per)))
+            if obs is not None:
+                # the p-free part of the host summary needs the observed X @ V only: formed here,
+                # while the device runs the kernels enqueued above, not after the last download
+                early["left"] = self._W @ obs["XV"]()[inds]
 
         def finish():
             Vh = V
             if obs is not None:
                 _, _, Vh = obs["host"]()
             got = pending[0].get()
-            return self._bootstrap_test_finish(got[0], got[1], got[2:], inds, Vh, Tvsc_orig, CI, keep_right_sv)
+            return self._bootstrap_test_finish(got[0], got[1], got[2:], inds, Vh, Tvsc_orig, CI, keep_right_sv,
+                                               left=early.get("left"))
         return tail, finish
 
-    def _bootstrap_test_finish(self, std_errs, boot_ratios, per, inds, V, Tvsc_orig, CI, keep_right_sv):
+    def _bootstrap_test_finish(self, std_errs, boot_ratios, per, inds, V, Tvsc_orig, CI, keep_right_sv,
+                               left=None):
         eng = self._engine
         # Tdistrib[i] = cell means of X @ normalize(VS_i)  (:623, :633-634)
         norms = np.sqrt(per[0])                                       # R x k
@@ -455,11 +463,12 @@ class _ResampleTestPLS(ResampleTest):
         conf_int = (Tvsc_orig - half, Tvsc_orig + half)               # :717
 
         # left_sv_sampled[i] = permuted_i @ V = W P_i (X V)   (:617, :631) -- p-free
-        if self._obs is not None and self._C is None:
-            XV = self._obs["XV"]()                                    # already formed for X_latent
-        else:
-            XV = eng.latents(V)                                       # X @ V on the device (K5, one item)
-        left = self._W @ XV[inds]                                     # (c,r)(b,r,k) -> b,c,k
+        if left is None:
+            if self._obs is not None and self._C is None:
+                XV = self._obs["XV"]()                                # already formed for X_latent
+            else:
+                XV = eng.latents(V)                                   # X @ V on the device (K5, one item)
+            left = self._W @ XV[inds]                                 # (c,r)(b,r,k) -> b,c,k
         debug = {
             "left_sv_sampled": left,
             "right_sv_sampled": per[2] if keep_right_sv else None,

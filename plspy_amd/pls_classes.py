@@ -139,12 +139,30 @@ class _MeanCentreTaskPLS(PLSBase):
         from . import dist, resample
         box = {}
         dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        cur = torch.cuda.current_stream() if dev is not None else None    # the helper thread enqueues on the caller's stream
+
+        Wm = operators.cell_mean_operator(co)
+        W = operators.mean_centre_operator(co, self.mctype)
 
         def upload():
             try:
                 if dev is not None:
                     torch.cuda.set_device(dev)
-                box["engine"] = ProjectionEngine(X, device=None if dev is None else f"cuda:{dev}")
+                    torch.cuda.set_stream(cur)
+                engine = box["engine"] = ProjectionEngine(X, device=None if dev is None else f"cuda:{dev}")
+                # observed decomposition (pls_classes.py:258-266), on the device: the
+                # two k x p blocks come from the projection kernel, the thin SVD
+                # (class_functions.py:122) from the Gram + Jacobi + back-projection
+                # kernels (engine.thin_svd).  Enqueued from this thread, right behind the upload (or at
+                # once when X is already on the device), so that the device is busy while the
+                # other thread still draws.  Nothing here waits for a result: the observed
+                # blocks, the decomposition and the latent scores stay on the device for the resampling
+                # phases (U for the operators, V s as the moment shift, the cell means for Tdistrib) and
+                # travel to the host in page-locked buffers behind the kernels (engine.fetch_async).
+                blocks = engine.apply_operator(np.vstack((Wm, W)))       # (2 cells, p) on the device
+                svd = engine.thin_svd_device(W)
+                Zt = engine.latents_device(svd["Vt"])                    # (X @ V)^T on the device (K5)
+                box["observed"] = (blocks, svd, engine.fetch_async([blocks, svd["U"], svd["s"], svd["Vt"], Zt]))
             except BaseException as e:                       # re-raised in the caller's thread
                 box["error"] = e
         th = threading.Thread(target=upload)
@@ -159,20 +177,7 @@ class _MeanCentreTaskPLS(PLSBase):
         if "error" in box:
             raise box["error"]
         engine = box["engine"]
-        # observed decomposition (pls_classes.py:258-266), on the device: the
-        # two k x p blocks come from the projection kernel, the thin SVD
-        # (class_functions.py:122) from the Gram + Jacobi + back-projection
-        # kernels (engine.thin_svd)
-        Wm = operators.cell_mean_operator(co)
-        W = operators.mean_centre_operator(co, self.mctype)
-        # Everything below is enqueued without the host waiting for a result: the observed
-        # blocks, the decomposition and the latent scores stay on the device for the resampling
-        # phases (U for the operators, V s as the moment shift, the cell means for Tdistrib) and
-        # travel to the host in page-locked buffers behind the kernels (engine.fetch_async).
-        blocks = engine.apply_operator(np.vstack((Wm, W)))           # (2 cells, p) on the device
-        svd = engine.thin_svd_device(W)
-        Zt = engine.latents_device(svd["Vt"])                        # (X @ V)^T on the device (K5)
-        fetch = engine.fetch_async([blocks, svd["U"], svd["s"], svd["Vt"], Zt])
+        blocks, svd, fetch = box["observed"]
         got = {}
 
         def host():
