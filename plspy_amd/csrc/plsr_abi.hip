@@ -5,6 +5,7 @@
 #include "plsr_project.hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -338,7 +339,24 @@ ProjectKernel boot_reg_instance(int nk) {
   }
 }
 
-int launch_boot_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
+// One-dimensional grid in XCD-aware order (reg_tile_and_run) for the kernels in `level`:
+// 1 = K1r (default: its fetches drop from 705 to 89 MB per launch at config 2, same duration),
+// 2 = K1br as well (fetches 665 -> 461 MB, but 1 % slower: with every run of a tile active at once the
+// 2.9 MB of operator fragments compete with 1.1 GB of slab stores for the XCD's 4 MB of L2).
+// PLSR_XCD_ORDER=0 / 1 / 2 overrides (measurement knob).
+dim3 reg_grid(ProjectArgs &a, int64_t nvt, int nrun, int level) {
+  static const int enabled = [] {
+    const char *e = getenv("PLSR_XCD_ORDER");
+    return e ? atoi(e) : 1;
+  }();
+  const int64_t nwg = (nvt + 7) / 8 * 8 * nrun;
+  if (enabled < level || nwg > 0x7fffffff) return dim3((unsigned)nvt, (unsigned)nrun);
+  a.xcd_runs = nrun;
+  a.nvt = nvt;
+  return dim3((unsigned)nwg);
+}
+
+int launch_boot_reg(ProjectArgs a, int64_t nvt, hipStream_t st) {
   const int nh = (a.k2 + 3) / 4;
   ProjectKernel kern = a.vs_dump ? boot_reg_instance<true, -1>(a.nk)
                        : nh == 1 ? boot_reg_instance<false, 1>(a.nk)
@@ -353,7 +371,8 @@ int launch_boot_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
     tl.kind = 1;
     (void)hipEventRecord(tl.a, st);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nvt, (unsigned)(a.k * a.msplit)), dim3(64), lds, st, a);
+  const dim3 grid = reg_grid(a, nvt, a.k * a.msplit, 2);
+  hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, a);
   if (g_timing) {
     (void)hipEventRecord(tl.b, st);
     g_timed.push_back(tl);
@@ -369,7 +388,7 @@ int perm_reg_split(int ntiles, int64_t nvt) {
   return std::min(nsplit, std::max(1, ntiles / 8));
 }
 
-int launch_perm_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
+int launch_perm_reg(ProjectArgs a, int64_t nvt, hipStream_t st) {
   const int nsplit = perm_reg_split(a.ntiles, nvt);
   ProjectKernel kern = nullptr;
   switch (a.nk) {
@@ -395,7 +414,8 @@ int launch_perm_reg(const ProjectArgs &a, int64_t nvt, hipStream_t st) {
     tl.kind = 0;
     (void)hipEventRecord(tl.a, st);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nvt, (unsigned)nsplit), dim3(64), 0, st, a);
+  const dim3 grid = reg_grid(a, nvt, nsplit, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(64), 0, st, a);
   if (g_timing) {
     (void)hipEventRecord(tl.b, st);
     g_timed.push_back(tl);

@@ -60,7 +60,28 @@ struct ProjectArgs {
   int32_t tpl, msplit;  // tiles per latent variable; splits of a latent variable's tiles (grid.y = k * msplit)
   const double *opsum;  // [4 nk][k] sum over the batch of the operators (S1 by linearity)
   double *sink;         // [64] scratch target of the lanes that have nothing to store (see K1r)
+  // register-resident kernels, XCD-aware dispatch order (reg_tile_and_run): runs per voxel tile, voxel tiles
+  int32_t xcd_runs;
+  int64_t nvt;
 };
+
+// K1r / K1br: workgroup -> (voxel tile, run).  With A.xcd_runs set the grid is one-dimensional and
+// workgroup ids go round the eight XCDs, so id % 8 picks the XCD: a voxel tile's runs are then neighbours
+// on ONE XCD (run index fastest) and its X tile is fetched from HBM once, not once per run (at config 2 the
+// re-reads were 0.57 GB of K1br's 0.67 GB of fetches, 0.6 of K1r's 0.7).  Returns false for the padding.
+__device__ __forceinline__ bool reg_tile_and_run(const ProjectArgs &A, int64_t &vt, int &run, int &nrun) {
+  if (A.xcd_runs > 0) {
+    const int64_t wg = blockIdx.x, in_xcd = wg >> 3;
+    nrun = A.xcd_runs;
+    run = (int)(in_xcd % nrun);
+    vt = (in_xcd / nrun) * 8 + (wg & 7);
+    return vt < A.nvt;
+  }
+  vt = blockIdx.x;
+  run = blockIdx.y;
+  nrun = gridDim.y;
+  return true;
+}
 
 __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -439,7 +460,9 @@ __global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) 
   const int lane = threadIdx.x;
   const int col = lane & 15;
   const int g = lane >> 4;
-  const int64_t vt = blockIdx.x;
+  int64_t vt;
+  int run, nrun;
+  if (!reg_tile_and_run(A, vt, run, nrun)) return;
   const int64_t v0 = vt * TV;
 
   double xa[NK][NT];
@@ -452,8 +475,8 @@ __global__ __launch_bounds__(64, 2) void project_perm_reg_kernel(ProjectArgs A) 
       xa[s][nt] = (row < A.n && v < A.p) ? A.X[(int64_t)row * A.ldx + v] : 0.0;
     }
 
-  const int per = (A.ntiles + gridDim.y - 1) / gridDim.y;
-  const int t_lo = blockIdx.y * per;
+  const int per = (A.ntiles + nrun - 1) / nrun;
+  const int t_lo = run * per;
   const int t_hi = min(A.ntiles, t_lo + per);
   if (t_lo >= t_hi) return;
   const int64_t C = (int64_t)A.ntiles * 16;
@@ -534,10 +557,12 @@ __global__ __launch_bounds__(64, (NK >= 16 || (DUMP && NK >= 12)) ? 1 : 2) void 
   const int lane = threadIdx.x;
   const int col = lane & 15;
   const int g = lane >> 4;
-  const int64_t vt = blockIdx.x;
+  int64_t vt;
+  int run, nrun;
+  if (!reg_tile_and_run(A, vt, run, nrun)) return;
   const int64_t v0 = vt * TV;
-  const int j = blockIdx.y / A.msplit;         // latent variable of this run
-  const int mi = blockIdx.y % A.msplit;
+  const int j = run / A.msplit;                // latent variable of this run
+  const int mi = run % A.msplit;
   const int nh = NHT >= 0 ? NHT : (A.k2 + 3) / 4;
 
   double xa[NK][NT];
