@@ -498,6 +498,55 @@ class _ResampleTestPLS(ResampleTest):
             raise Exception(_DEGENERATE)                                               # :572
         return np.concatenate(got, axis=1) if multiblock else got[0]
 
+    def _upload_in_background(self, make):
+        """Form a large host array (the observed V s, p x k) and upload it from a helper thread while
+        the caller draws the bootstrap indices and runs the degenerate-Y guard (both single-threaded
+        host work, 8 + 11 ms at config 3).  Returns a function that joins and hands over the
+        device tensor."""
+        import threading
+        import torch
+        eng = self._engine
+        box = {}
+        dev, cur = torch.cuda.current_device(), torch.cuda.current_stream()
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                torch.cuda.set_stream(cur)
+                box["t"] = eng.dev(make())
+            except BaseException as e:                       # re-raised in the caller's thread
+                box["error"] = e
+        th = threading.Thread(target=work)
+        th.start()
+
+        def get():
+            th.join()
+            if "error" in box:
+                raise box["error"]
+            return box["t"]
+        return get
+
+    class _RunningStd:
+        """np.std(axis=0) of per-resample rows that arrive batch by batch: sums about the first row,
+        accumulated while the device works on the next batch instead of one pass over the whole
+        (niter, rows, k) array after the last one (6 ms at config 3).  The shift keeps the one-pass
+        formula at a few ulp for these O(1) correlations / cell means."""
+
+        def __init__(self):
+            self.n, self.shift, self.s1, self.s2 = 0, None, 0.0, 0.0
+
+        def add(self, rows):
+            if self.shift is None:
+                self.shift = rows[0].copy()
+            d = rows - self.shift
+            self.s1 = self.s1 + d.sum(axis=0)
+            self.s2 = self.s2 + np.einsum("i...,i...->...", d, d)
+            self.n += len(rows)
+
+        def std(self):
+            m = self.s1 / self.n
+            return np.sqrt(np.maximum(self.s2 / self.n - m * m, 0.0))
+
     @staticmethod
     def _normalised_latents(zt, nsq):
         """X @ normalize(VS_b) (:623) for a batch, from (X VS_b)^T (cnt, k, n) and the
@@ -544,11 +593,12 @@ class _ResampleTestPLS(ResampleTest):
         n, b = Y.shape
         k = U.shape[1]
         bounds = cf.cell_bounds(co)
+        ref_ready = self._upload_in_background(lambda: V * s)
         inds = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Y, False))
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
         mine = inds[lo:hi]
-        ref = V * s
+        ref = ref_ready()
 
         def ops_fn(a, z, _):
             # op_b[j, i] = sum_beh Yz_b[i, beh] U[(cell(i), beh), j]:  VS_b = R_b^T U with
@@ -560,19 +610,27 @@ class _ResampleTestPLS(ResampleTest):
             return ops
 
         LVc = np.empty((hi - lo, (len(bounds) - 1) * b, k))
+        spread = self._RunningStd()
+        yz_of = {}                                   # a batch's z-scored behaviour: formed once, used twice
+
+        def yz(a, z):
+            if (a, z) not in yz_of:
+                yz_of[a, z] = cf.zscore_cells(Y[mine[a:z]], bounds)
+            return yz_of[a, z]
 
         def on_batch(a, z, zt, nsq):
             # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
             # (no transposes, and no division by the column norms: see lvcorr_from_latents)
             Lt = np.take_along_axis(zt, mine[a:z][:, None, :].astype(np.int64), axis=2)
-            LVc[a:z] = cf.lvcorr_from_latents(Lt, cf.zscore_cells(Y[mine[a:z]], bounds), bounds)
+            LVc[a:z] = cf.lvcorr_from_latents(Lt, yz(a, z), bounds)
+            yz_of.pop((a, z), None)
+            spread.add(LVc[a:z])
 
         res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch,
-                             beh=(lambda a, z: cf.zscore_cells(Y[mine[a:z]], bounds), U),
-                             after_enqueue=self._finalize_early(niter, ref))
+                             beh=(yz, U), after_enqueue=self._finalize_early(niter, ref))
         std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
-        half = np.std(LVcorr, axis=0) * z                                      # :723-724
+        half = (spread.std() if nranks == 1 else np.std(LVcorr, axis=0)) * z    # :723-724
         conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :725
         debug = {"left_sv_sampled": LVcorr, "right_sv_sampled": None, "indices": inds}
         return conf_int, std_errs, boot_ratios, LVcorr, debug
@@ -595,11 +653,12 @@ class _ResampleTestPLS(ResampleTest):
         k = U.shape[1]                                 # latent variables
         bounds_b = cf.cell_bounds(co[:, bscan])
         brows = np.flatnonzero(cf.bscan_mask(co, bscan))                       # bscan index -> row of X
+        ref_ready = self._upload_in_background(lambda: V * s if self._C is None else V)
         draws = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Yb, True))
         ti, bi = draws[:, :n], draws[:, n:]
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
-        ref = V * s if self._C is None else V
+        ref = ref_ready()
         # item matrix = [X[ti] (raw) ; X[brows[bi]] z-scored within the bscan cells]
         src = np.concatenate((ti, brows[bi]), axis=1)[lo:hi]
         cell_lo = np.concatenate(([0, n], n + bounds_b[1:]))
@@ -632,6 +691,7 @@ class _ResampleTestPLS(ResampleTest):
         LVc = np.empty((cnt, (len(bounds_b) - 1) * b, k))
         Td = np.empty((cnt, co.size, k))
         bi_m, ti_m = bi[lo:hi], ti[lo:hi]
+        spread, spread_t = self._RunningStd(), self._RunningStd()
 
         def on_batch(a, z, zt, nsq):
             Zn = self._normalised_latents(zt, nsq)
@@ -645,14 +705,16 @@ class _ResampleTestPLS(ResampleTest):
             else:
                 # cmb (:665-666): cell means of X @ normalize(crossblock.T), X itself
                 Td[a:z] = cf.cell_means_rows(Zn, co)
+            spread.add(LVc[a:z])
+            spread_t.add(Td[a:z])
 
         res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n,
                              on_batch=on_batch, project_on=U, after_enqueue=self._finalize_early(niter, ref))
         std_errs, boot_ratios, (LVcorr, Tdistrib) = self._finish_items(res, [LVc, Td], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
-        half = np.std(LVcorr, axis=0) * z
+        half = (spread.std() if nranks == 1 else np.std(LVcorr, axis=0)) * z
         conf_int = (lvcorrs_orig - half, lvcorrs_orig + half)                  # :723-725
-        half_t = np.std(Tdistrib, axis=0) * z
+        half_t = (spread_t.std() if nranks == 1 else np.std(Tdistrib, axis=0)) * z
         conf_int_T = (Tvsc_orig - half_t, Tvsc_orig + half_t)                  # :732-734
         debug = {"left_sv_sampled": LVcorr, "right_sv_sampled": None, "indices": draws, "Tdistrib": Tdistrib}
         return conf_int, conf_int_T, std_errs, boot_ratios, LVcorr, debug

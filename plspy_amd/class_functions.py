@@ -47,8 +47,13 @@ def any_group_std_zero(Mb, cond_order):
         start += int(tot)
         if blk.shape[1] == 0:
             continue
-        # np.std == 0 exactly when every deviation from the mean is exactly 0
-        bad |= (np.std(blk, axis=1) == 0).any(axis=-1)
+        # np.std == 0 exactly when every deviation from the mean is exactly 0, which takes a constant
+        # column (but a constant column's mean may round away from the constant: the std decides).
+        # Constant columns are rare, so the two-pass std runs on the candidates only.
+        cand = (blk == blk[:, :1]).all(axis=1).any(axis=-1)
+        if cand.any():
+            at = np.flatnonzero(cand)
+            bad[at] |= (np.std(blk[at], axis=1) == 0).any(axis=-1)
     return bad
 
 
