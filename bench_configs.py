@@ -93,7 +93,7 @@ def main():
     elif args.config == 3:
         R = args.count or 2000
         X, Y = data(120, 200_000, 8)
-        res, t_obs = timed(lambda: plspy_amd.PLS(X, [20, 20], 3, Y=Y, num_perm=0, num_boot=0, pls_method="rb"))
+        res, t_obs = timed(lambda: plspy_amd.PLS(X, [20, 20], 3, Y=Y, num_perm=0, num_boot=0, pls_method="rb"), "observed")
         U, s, V = res.V, res.s.copy(), res.U
         co = np.array([[20] * 3, [20] * 3])
         eng = ProjectionEngine(X)

@@ -498,6 +498,15 @@ class _ResampleTestPLS(ResampleTest):
             raise Exception(_DEGENERATE)                                               # :572
         return np.concatenate(got, axis=1) if multiblock else got[0]
 
+    def _observed_vs(self, V, s):
+        """The observed V s (p x k) on the device, as a function to call once it is needed: a layout
+        copy of the (V s)^T the PLS classes left there (_observed), or formed from the host arrays
+        and uploaded in the background."""
+        if self._obs is not None and "VSt" in self._obs:
+            ref = self._obs["VSt"].t().contiguous()
+            return lambda: ref
+        return self._upload_in_background(lambda: V * s)
+
     def _upload_in_background(self, make):
         """Form a large host array (the observed V s, p x k) and upload it from a helper thread while
         the caller draws the bootstrap indices and runs the degenerate-Y guard (both single-threaded
@@ -589,11 +598,11 @@ class _ResampleTestPLS(ResampleTest):
         co = self._cond_order
         Y = np.asarray(self._Y, dtype=float)
         U = np.asarray(U, dtype=float)
-        V = np.asarray(V, dtype=float)
+        V = None if V is None else np.asarray(V, dtype=float)
         n, b = Y.shape
         k = U.shape[1]
         bounds = cf.cell_bounds(co)
-        ref_ready = self._upload_in_background(lambda: V * s)
+        ref_ready = self._observed_vs(V, s)
         inds = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Y, False))
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
@@ -643,7 +652,7 @@ class _ResampleTestPLS(ResampleTest):
         bscan = list(self._bscan)
         Yb = np.asarray(self._Ybscan, dtype=float)
         U = np.asarray(U, dtype=float) if self._C is None else self._C
-        V = np.asarray(V, dtype=float)
+        V = None if V is None else np.asarray(V, dtype=float)
         ng, nc = co.shape
         n = int(co.sum())
         nb, b = Yb.shape
@@ -653,7 +662,7 @@ class _ResampleTestPLS(ResampleTest):
         k = U.shape[1]                                 # latent variables
         bounds_b = cf.cell_bounds(co[:, bscan])
         brows = np.flatnonzero(cf.bscan_mask(co, bscan))                       # bscan index -> row of X
-        ref_ready = self._upload_in_background(lambda: V * s if self._C is None else V)
+        ref_ready = self._observed_vs(V, s) if self._C is None else self._upload_in_background(lambda: V)
         draws = self._draw_on_rank0(lambda: self._draw_boot_with_guard(niter, Yb, True))
         ti, bi = draws[:, :n], draws[:, n:]
         rank, nranks = dist.world()

@@ -252,16 +252,25 @@ class _RegularBehaviourPLS(PLSBase):
         Xz = engine.gather_zscore(np.arange(n), bounds, np.ones(len(bounds) - 1))[0]
         eng_z = ProjectionEngine(Xz, device=engine.device, work_limit=engine.work_limit)
         A = cf.corr_operator(cf.zscore_cells(np.asarray(Y, dtype=float), bounds), bounds)
-        self.R = eng_z.apply_operator(A).cpu().numpy()
-        self.U, self.s, self.V = eng_z.thin_svd(A)                     # :574
-        self.X_latent = engine.latents(self.V)                         # X @ V on the device (K5)
+        # The k x p blocks stay on the device (R, V^T, (V s)^T) and travel to the host in page-locked
+        # buffers behind the kernels: the host waits for the k x k part only (U, s: the resampling
+        # operators are formed from it), the 2 x 77 MB of R and V at config 3 arrive while the tests run.
+        Rd = eng_z.apply_operator(A)
+        svd = eng_z.thin_svd_device(A)                                 # :574
+        Zt = engine.latents_device(svd["Vt"])                          # (X @ V)^T on the device (K5)
+        small = engine.fetch_async([svd["U"], svd["s"], Zt])
+        large = engine.fetch_async([Rd, svd["Vt"]])
+        self.U, self.s, Zt_h = small.get()
+        self.X_latent = np.ascontiguousarray(Zt_h[0].T)
         self.Y_latent = cf.compute_Y_latents(self.Y, self.U, co)
         self.lvcorrs = cf.compute_corr_small(self.X_latent, self.Y, co)   # :581-583
 
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
-            self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, None,
+            self.pls_alg, self.X, self.Y, self.U, self.s, None, self.cond_order, None,
             preprocess=None, nperm=self.num_perm, nboot=self.num_boot, lvcorrs_orig=self.lvcorrs,
-            CI=self.CI, engine=engine)
+            CI=self.CI, engine=engine, _observed=dict(VSt=svd["VSt"]))
+        self.R, Vt_h = large.get()
+        self.V = Vt_h.T
 
         if "num_split" in self._user_defined_attrs:
             self.num_split = int(self.num_split)
@@ -334,15 +343,22 @@ class _MultiblockPLS(PLSBase):
         for g in range(ng):
             raw[g * per:g * per + nc, :n] = W[g * nc:(g + 1) * nc]
             raw[g * per + nc:(g + 1) * per, n:] = Ab[g * nbs * b:(g + 1) * nbs * b]
-        G = eng_c.gram_phase(raw[None])[0].cpu().numpy()
+        G = eng_c.fetch_async([eng_c.gram_phase(raw[None])[0]]).get()[0]
         rownorm = np.sqrt(np.diag(G)[:k])
         normed = raw / rownorm[:, None]                              # :503-505 folded into the operator
-        self.multiblock = eng_c.apply_operator(normed).cpu().numpy()
-        self.U, self.s, self.V = eng_c.thin_svd(normed)              # :1456
-
-        V_normed = cf.normalize(self.V)
-        T_X_latent = engine.latents(V_normed)                        # :1460-1461, on the device (K5)
-        B_X_latent = engine.latents(self.V)[mask]                    # :1464  Xbscan @ V = (X @ V)[bscan rows]
+        # (as in the behaviour class: only U, s and the latent scores are waited for; the k x p
+        # multiblock and V arrive in page-locked buffers while the tests run)
+        Md = eng_c.apply_operator(normed)
+        svd = eng_c.thin_svd_device(normed)                          # :1456
+        Zt = engine.latents_device(svd["Vt"])                        # (X @ V)^T on the device (K5)
+        small = engine.fetch_async([svd["U"], svd["s"], Zt])
+        large = engine.fetch_async([Md, svd["Vt"]])
+        self.U, self.s, Zt_h = small.get()
+        XV = np.ascontiguousarray(Zt_h[0].T)                         # X @ V
+        # X @ normalize(V) (:1460-1461) = (X @ V) / ||V_j||, and ||V_j|| = 1 for every live latent
+        # variable, 0 (column of zeros, left alone by normalize) for a deflated one
+        T_X_latent = XV
+        B_X_latent = XV[mask]                                        # :1464  Xbscan @ V = (X @ V)[bscan rows]
         self.X_latent = np.vstack((T_X_latent, B_X_latent))
         self.usc, self.Tusc, self.Busc = self.X_latent, T_X_latent, B_X_latent
         Tu, Bu = cf.split_Tu_Bu(self.U, num_conditions, self.Y.shape[1], ng, nbs)
@@ -355,10 +371,12 @@ class _MultiblockPLS(PLSBase):
         self.lvcorrs = cf.compute_corr_small(B_X_latent, self.Ybscan, co[:, bscan])   # :1499-1501
 
         self.resample_tests = bootstrap_permutation.ResampleTest._create(
-            self.pls_alg, self.X, self.Y, self.U, self.s, self.V, self.cond_order, self.mctype,
+            self.pls_alg, self.X, self.Y, self.U, self.s, None, self.cond_order, self.mctype,
             preprocess=None, nperm=self.num_perm, nboot=self.num_boot, bscan=self.bscan,
             Xbscan=self.Xbscan, Ybscan=self.Ybscan, lvcorrs_orig=self.lvcorrs,
-            Tvsc_orig=Tvsc_orig, CI=self.CI, engine=engine)
+            Tvsc_orig=Tvsc_orig, CI=self.CI, engine=engine, _observed=dict(VSt=svd["VSt"]))
+        self.multiblock, Vt_h = large.get()
+        self.V = Vt_h.T
 
         if "num_split" in self._user_defined_attrs:
             self.num_split = int(self.num_split)
