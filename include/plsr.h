@@ -138,6 +138,14 @@ int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p,
                     void *d_work, size_t work_bytes, void *stream);
 
 /*
+ * out[r][c] = in[r][c] * scale[c] for a row-major (rows x cols) matrix: the observed V s
+ * (the shift of the bootstrap moments and the numerator of boot_ratios,
+ * bootstrap_permutation.py:695-703) from V and s where only those are at hand.  In place allowed.
+ */
+int plsr_scale_cols(const double *d_in, int64_t rows, int32_t cols, const double *d_scale,
+                    double *d_out, void *stream);
+
+/*
  * Bootstrap summary from the streamed moments (bootstrap_permutation.py:695-703):
  *     std[e]   = sqrt( max( S2[e]/R - (S1[e]/R)^2 , 0 ) )      np.std, ddof = 0
  *     ratio[e] = num[e] / std[e]                               boot_ratios

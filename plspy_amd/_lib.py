@@ -38,6 +38,7 @@ SIGNATURES = {
     "plsr_boot_batch": (c_i32, [c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(Layout), c_vp, c_vp,
                                 c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_boot_finalize": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "plsr_scale_cols": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "plsr_rows_frag_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "plsr_ops_pack_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "plsr_gram_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64, c_i64]),

@@ -274,14 +274,15 @@ class _ResampleTestPLS(ResampleTest):
         cond_order even on the bscan subset, quirk Q8)."""
         co = self._cond_order
         nrows = Ysrc.shape[0]
+        is_bad = cf.degenerate_guard(Ysrc, co)
         if with_task:
             got = resample.draw_guarded(
                 niter, lambda m: resample.mb_permutation_tries(co, nrows, m),         # :343, :347
-                lambda task, rows: cf.any_group_std_zero(Ysrc[rows], co))
+                lambda task, rows: is_bad(rows))
         else:
             got = resample.draw_guarded(
                 niter, lambda m: (resample.permutations(nrows, m),),                  # :338
-                lambda rows: cf.any_group_std_zero(Ysrc[rows], co))
+                is_bad)
         if got is None:
             raise Exception(_DEGENERATE)                                               # :355
         return np.concatenate(got, axis=1) if with_task else got[0]
@@ -486,14 +487,15 @@ class _ResampleTestPLS(ResampleTest):
         resampled Y is 0 (guard on the full cond_order, quirk Q8).  rb: one draw
         per try; mb: task draw then bscan draw per try (:547-553, quirk Q7)."""
         co = self._cond_order
+        is_bad = cf.degenerate_guard(Ysrc, co)                                          # :563-564
         if multiblock:
             got = resample.draw_guarded(
                 niter, lambda m: resample.mb_bootstrap_tries(co, self._bscan, m),     # :547, :551
-                lambda ti, bi: cf.any_group_std_zero(Ysrc[bi], co))                    # :563-564
+                lambda ti, bi: is_bad(bi))
         else:
             got = resample.draw_guarded(
                 niter, lambda m: (resample.bootstraps(co, m),),                       # :557
-                lambda bi: cf.any_group_std_zero(Ysrc[bi], co))
+                is_bad)
         if got is None:
             raise Exception(_DEGENERATE)                                               # :572
         return np.concatenate(got, axis=1) if multiblock else got[0]
@@ -505,9 +507,10 @@ class _ResampleTestPLS(ResampleTest):
         if self._obs is not None and "VSt" in self._obs:
             ref = self._obs["VSt"].t().contiguous()
             return lambda: ref
-        return self._upload_in_background(lambda: V * s)
+        eng = self._engine
+        return self._upload_in_background(lambda: eng.scale_cols(V, s), upload=False)
 
-    def _upload_in_background(self, make):
+    def _upload_in_background(self, make, upload=True):
         """Form a large host array (the observed V s, p x k) and upload it from a helper thread while
         the caller draws the bootstrap indices and runs the degenerate-Y guard (both single-threaded
         host work, 8 + 11 ms at config 3).  Returns a function that joins and hands over the
@@ -522,7 +525,7 @@ class _ResampleTestPLS(ResampleTest):
             try:
                 torch.cuda.set_device(dev)
                 torch.cuda.set_stream(cur)
-                box["t"] = eng.dev(make())
+                box["t"] = eng.dev(make()) if upload else make()
             except BaseException as e:                       # re-raised in the caller's thread
                 box["error"] = e
         th = threading.Thread(target=work)

@@ -57,6 +57,35 @@ def any_group_std_zero(Mb, cond_order):
     return bad
 
 
+def degenerate_guard(Ysrc, cond_order):
+    """is_bad(rows) for a stack of index vectors rows (m, n): any_group_std_zero(Ysrc[rows], cond_order)
+    without gathering m x n x b numbers when the answer can be read off the indices.  If no column of
+    Ysrc holds the same value twice, a group's column is constant only when the group repeats ONE source
+    row throughout (never for a permutation, rarely for a bootstrap): those candidates are found on the
+    integer table, and only they go through the exact test.  Columns with repeated values (or NaNs:
+    np.unique folds them) take the full test."""
+    Ysrc = np.asarray(Ysrc)
+    cond_order = np.asarray(cond_order)
+    distinct = all(len(np.unique(Ysrc[:, c])) == Ysrc.shape[0] for c in range(Ysrc.shape[1]))
+
+    def is_bad(rows):
+        if not distinct:
+            return any_group_std_zero(Ysrc[rows], cond_order)
+        cand = np.zeros(rows.shape[0], dtype=bool)
+        start = 0
+        for tot in cond_order.sum(axis=1):
+            blk = rows[:, start:start + int(tot)]
+            start += int(tot)
+            if blk.shape[1]:
+                cand |= (blk == blk[:, :1]).all(axis=1)
+        bad = np.zeros(rows.shape[0], dtype=bool)
+        if cand.any():
+            at = np.flatnonzero(cand)
+            bad[at] = any_group_std_zero(Ysrc[rows[at]], cond_order)
+        return bad
+    return is_bad
+
+
 def zscore_cells(M, bounds):
     """Per-cell z-score (ddof 0) divided by sqrt(n_cell), constant columns -> 0:
     what class_functions.py:221-238 does to X and to Y (scipy.stats.zscore's

@@ -558,6 +558,15 @@ extern "C" int plsr_boot_batch(const double *d_X, int64_t ldx, int64_t p, const 
   return rc;
 }
 
+extern "C" int plsr_scale_cols(const double *d_in, int64_t rows, int32_t cols, const double *d_scale,
+                               double *d_out, void *stream) {
+  if (!d_in || !d_scale || !d_out || rows <= 0 || cols <= 0) return PLSR_EINVAL;
+  const int64_t count = rows * cols;
+  dim3 grid((unsigned)((count + 255) / 256));
+  hipLaunchKernelGGL(scale_cols_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_in, d_scale, count, cols, d_out);
+  return check_launch();
+}
+
 extern "C" int plsr_boot_finalize(const double *d_S1, const double *d_S2, const double *d_num,
                                   int64_t count, int32_t R, double *d_std, double *d_ratio,
                                   void *stream) {

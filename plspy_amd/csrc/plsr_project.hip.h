@@ -1011,4 +1011,12 @@ __global__ __launch_bounds__(256) void boot_finalize_kernel(const double *S1, co
   if (ratio != nullptr) ratio[e] = num[e] / s;
 }
 
+// out[r][c] = in[r][c] * scale[c]  (the observed V s from V and s: bootstrap_permutation.py:695, :701)
+__global__ __launch_bounds__(256) void scale_cols_kernel(const double *in, const double *scale, int64_t count,
+                                                         int cols, double *out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  out[e] = in[e] * scale[e % cols];
+}
+
 }  // namespace plsr

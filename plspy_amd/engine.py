@@ -278,6 +278,18 @@ class ProjectionEngine:
                    "plsr_boot_finalize")
         return sd, ratio
 
+    def scale_cols(self, M, scale):
+        """M (rows x cols, host or device) times scale per column, on the device: the observed V s
+        from V and s.  A host array's device copy is scaled in place; a device tensor is left alone."""
+        Md = self.dev(M).contiguous()
+        out = Md if isinstance(M, np.ndarray) else torch.empty_like(Md)
+        sd = self.dev(np.ascontiguousarray(scale, dtype=np.float64) if isinstance(scale, np.ndarray) else scale)
+        if Md.dim() != 2 or sd.numel() != Md.shape[1]:
+            raise ValueError("scale_cols: one scale per column")
+        _lib.check(self.lib.plsr_scale_cols(_ptr(Md), Md.shape[0], Md.shape[1], _ptr(sd), _ptr(out), _stream()),
+                   "plsr_scale_cols")
+        return out
+
     def apply_operator(self, rows):
         """(m x n) operator rows -> (m x p) = rows @ X on the device (K0; the observed
         cell means / centred block / correlation block / back-projection)."""

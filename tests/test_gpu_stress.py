@@ -349,3 +349,18 @@ def test_latents_random_shapes():
         got = ProjectionEngine(X).latents(V)
         want = X @ V
         np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11 * np.abs(want).max(), err_msg=f"{n} {p} {k}")
+
+
+@pytest.mark.gpu
+def test_scale_cols_matches_numpy():
+    """plsr_scale_cols: V * s for host and device inputs (the device input is left untouched)."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(3)
+    eng = ProjectionEngine(rs.randn(4, 70))
+    for rows, cols in ((1, 1), (1001, 7), (5000, 48)):
+        V, s = rs.randn(rows, cols), rs.randn(cols)
+        assert np.array_equal(eng.scale_cols(V, s).cpu().numpy(), V * s)
+        Vd = torch.as_tensor(V).cuda()
+        assert np.array_equal(eng.scale_cols(Vd, torch.as_tensor(s).cuda()).cpu().numpy(), V * s)
+        assert np.array_equal(Vd.cpu().numpy(), V)

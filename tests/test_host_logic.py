@@ -130,3 +130,26 @@ def test_assert_close_rejects_non_finite_mismatch():
                       ([np.inf], [-np.inf]), ([1.0], [1.1])):
         with pytest.raises(AssertionError):
             assert_close(got, want, 1e-10)
+
+
+def test_degenerate_guard_matches_full_test():
+    """cf.degenerate_guard (index shortcut) == any_group_std_zero on the gathered stack: distinct
+    columns (bootstrap draws that repeat one row through a group), columns with repeated values,
+    and the tolerant slicing of a cond_order longer than the rows (quirk Q8)."""
+    from plspy_amd import class_functions as cf
+    rs = np.random.RandomState(5)
+    co = np.array([[2, 2], [3, 1]])
+    n = int(co.sum())
+    for Y in (rs.randn(n, 3), np.round(rs.randn(n, 3)), np.where(rs.rand(n, 3) < 0.2, np.nan, rs.randn(n, 3))):
+        rows = rs.randint(0, n, size=(400, n))
+        rows[5, :4] = 3                      # first group: one row repeated
+        rows[9, 4:] = 0                      # second group
+        rows[11] = np.arange(n)
+        want = cf.any_group_std_zero(Y[rows], co)
+        assert np.array_equal(cf.degenerate_guard(Y, co)(rows), want)
+        assert want[5] and want[9] or np.isnan(Y).any()
+    # bscan subset: fewer rows than cond_order describes
+    Yb = rs.randn(5, 2)
+    rows = rs.randint(0, 5, size=(300, 5))
+    rows[7, :4] = 2
+    assert np.array_equal(cf.degenerate_guard(Yb, co)(rows), cf.any_group_std_zero(Yb[rows], co))
