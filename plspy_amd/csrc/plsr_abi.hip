@@ -659,9 +659,9 @@ bool gram_plan(int32_t n, int32_t m, int32_t items, int64_t p, bool per_item_x, 
   return true;
 }
 
-template <int MC, int B, bool FUSED = false>
+template <int MC, int B, bool FUSED = false, int SL = 0, int SH = MC>
 int launch_gram(const GramArgs &a, const GramPlan &g, hipStream_t st) {
-  auto kern = gram_kernel<MC, B, FUSED>;
+  auto kern = gram_kernel<MC, B, FUSED, SL, SH>;
   if (g.lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
@@ -719,6 +719,8 @@ extern "C" int plsr_gram_batch(const double *d_X, int64_t x_item_stride, int64_t
   a.rowcell = nullptr;
   a.ncell = 0;
   a.sc = a.sh = nullptr;
+  a.act = nullptr;
+  a.rowtab = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int rc = PLSR_EUNSUPPORTED;
 #define PLSR_G(MCv, Bv) \

@@ -42,7 +42,23 @@ struct GramArgs {
   const int32_t *rowcell;    // [n] cell of every row
   int32_t ncell;
   const double *sc, *sh;     // [items][ncell][p]
+  // block-sparse operators (template SL / SH): bit s of act[0] -- some item's operator is non-zero in
+  // k-step s of a tile below SL; act[1] -- of a tile from SH on (gram_activity_kernel)
+  const uint64_t *act;
+  // FUSED: per (item, row) the element offsets of the row's source row in X and of its cell's scale /
+  // shift rows in sc / sh (gram_rowtab_kernel): [items][n] pairs, read through the scalar cache
+  const int64_t *rowtab;
 };
+
+// rowtab[item][row] = { src[item][row] * ldx,  (item * ncell + rowcell[row]) * p }
+__global__ __launch_bounds__(256) void gram_rowtab_kernel(const int32_t *src, const int32_t *rowcell, int items, int n,
+                                                          int ncell, int64_t ldx, int64_t p, int64_t *tab) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)items * n) return;
+  const int item = (int)(e / n), row = (int)(e % n);
+  tab[2 * e] = (int64_t)src[e] * ldx;
+  tab[2 * e + 1] = ((int64_t)item * ncell + rowcell[row]) * p;
+}
 
 constexpr int GRAM_PF = 20;   // rows of X a thread parks in registers per K-chunk (ks <= GRAM_PF)
 // ... except for six-tile items that stage their own gathered / z-scored rows (m = 81..96, e.g.
@@ -50,10 +66,44 @@ constexpr int GRAM_PF = 20;   // rows of X a thread parks in registers per K-chu
 // 124 bytes per lane at 20 rows (16 at 10); 8 rows fit
 constexpr int gram_pf(int mc, bool own_rows) { return (own_rows && mc >= 6) ? 8 : GRAM_PF; }
 
-// MC = 16-row tiles per item, B = items per workgroup
-template <int MC, int B, bool FUSED = false>
+// Which k-steps of which tile groups carry anything: the operator rows of a split-half item are two
+// halves that touch disjoint source rows (split_half_resampling._items_rb / _items_mb), so half of the
+// first product's MFMAs would multiply zeros.  Tiles [0, SL) form the LOW group, [SL, SH) are always
+// computed, [SH, MC) form the HIGH group; a k-step skips a group none of whose operator fragments (over
+// all items of the launch) holds a non-zero.  Found from the fragments themselves, so any operator is
+// handled correctly -- a dense one just gets all-ones masks.
+__global__ __launch_bounds__(256) void gram_activity_kernel(const double *frag, int64_t total, int MC, int nk, int SL,
+                                                            int SH, unsigned long long *act) {
+  unsigned long long lo = 0, hi = 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    if (frag[e] != 0.0) {
+      const int64_t ts = e >> 6;                          // (item * MC + tile) * nk + step
+      const int step = (int)(ts % nk), tile = (int)((ts / nk) % MC);
+      if (tile < SL) lo |= 1ull << step;
+      if (tile >= SH) hi |= 1ull << step;
+    }
+  }
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    lo |= __shfl_xor(lo, sft);
+    hi |= __shfl_xor(hi, sft);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (lo) atomicOr(act, lo);
+    if (hi) atomicOr(act + 1, hi);
+  }
+}
+
+// MC = 16-row tiles per item, B = items per workgroup; SL / SH: see gram_activity_kernel (0 / MC: dense)
+template <int MC, int B, bool FUSED = false, int SL = 0, int SH = MC>
 __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
   static_assert(!FUSED || B == 1, "fused items do not share a tile");
+  static_assert(0 <= SL && SL <= SH && SH <= MC, "tile groups");
+  constexpr bool SPARSE = SL > 0 || SH < MC;
+  unsigned long long act_lo = ~0ull, act_hi = ~0ull;
+  if (SPARSE) {
+    act_lo = A.act[0];
+    act_hi = A.act[1];
+  }
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NG = MC * (MC + 1) / 2;
   constexpr int MM = MC * 16;
@@ -113,29 +163,16 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
   };
   constexpr int PF = gram_pf(MC, FUSED);
   double px[PF], psc[FUSED ? PF : 1], psh[FUSED ? PF : 1];
-  // FUSED: the item's source-row and cell tables (n <= 256 entries each) live in four
-  // vector registers apiece, entry r in lane r & 63 of register r >> 6; a row's entry
-  // comes out through v_readlane.  Read from memory per row they were dependent loads
-  // in front of every X load -- one L2 round trip per row, which cost more than the
-  // MFMAs of a chunk.
-  int sreg[4] = {0, 0, 0, 0}, creg[4] = {0, 0, 0, 0};
-  if (FUSED) {
-    const int32_t *srci = A.src + (int64_t)item0 * A.n;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = q * 64 + lane;
-      sreg[q] = idx < A.n ? srci[idx] : 0;
-      creg[q] = idx < A.n ? A.rowcell[idx] : 0;
-    }
-  }
-  auto pick = [&](const int (&t)[4], int row) {          // row is wave-uniform
-    const int l = row & 63, qd = row >> 6;
-    // four v_readlane and scalar selects (a select between the vector registers
-    // compiled to a chain of branches)
-    const int r0 = __builtin_amdgcn_readlane(t[0], l), r1 = __builtin_amdgcn_readlane(t[1], l);
-    const int r2 = __builtin_amdgcn_readlane(t[2], l), r3 = __builtin_amdgcn_readlane(t[3], l);
-    return qd == 0 ? r0 : (qd == 1 ? r1 : (qd == 2 ? r2 : r3));
-  };
+  bool pvin = true;
+  // FUSED: a row's two offsets come from the item's row table through the SCALAR cache (one
+  // s_load_dwordx4 per row: the table is addressed as constant memory, the row index is wave-uniform),
+  // and the three loads of a row share one per-lane voxel offset.  (Round 1 kept the source-row and
+  // cell tables in vector registers and picked entries with v_readlane: ninety-odd instructions per
+  // row with the 64-bit address arithmetic -- 4 700 per voxel tile and wave, more issue time than the
+  // tile's MFMAs take.)
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  const __attribute__((address_space(4))) i64x2 *rowtab =
+      (const __attribute__((address_space(4))) i64x2 *)(uintptr_t)(A.rowtab + (FUSED ? (int64_t)item0 * A.n * 2 : 0));
   auto fetch = [&](Pos q) {
     const int ks1 = min(A.nk, q.ks0 + A.ks);
     const int64_t v = q.vt * TV + lane;
@@ -144,20 +181,18 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
     if (FUSED) {
       const int rpw = (4 * (ks1 - q.ks0) + WAVES - 1) / WAVES;
       const int rbeg = 4 * q.ks0 + wave * rpw;
-      const int rend = min(4 * ks1, rbeg + rpw);
+      // rows past the wave's share or past n are fetched from a clamped row and never parked; voxels
+      // past p (or a prefetch past the chunk) from a clamped voxel and parked as zeros (pvin)
+      const uint32_t vo = (uint32_t)vc;                  // (p < 2^29: scalar base + 32-bit lane offset)
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
-        const int row = rbeg + u;
-        const bool ok = row < rend && row < A.n;
-        const int rc = ok ? row : 0;
-        const int cell = pick(creg, rc);
-        const int64_t sidx = ((int64_t)item0 * A.ncell + cell) * A.p + vc;
-        const double x = A.X[(int64_t)pick(sreg, rc) * A.ldx + vc];
-        const double c = A.sc[sidx], h = A.sh[sidx];
-        px[u] = (ok && vin) ? x : 0.0;
-        psc[u] = (ok && vin) ? c : 0.0;
-        psh[u] = (ok && vin) ? h : 0.0;
+        const int rc = min(rbeg + u, A.n - 1);
+        const i64x2 t = rowtab[rc];
+        px[u] = (A.X + t.x)[vo];
+        psc[u] = (A.sc + t.y)[vo];
+        psh[u] = (A.sh + t.y)[vo];
       }
+      pvin = vin;
     } else {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -177,7 +212,8 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int row = rbeg + u;
-        if (row < rend) Xs[xs_index(row - 4 * q.ks0, lane)] = fma(px[u], psc[FUSED ? u : 0], psh[FUSED ? u : 0]);
+        const double z = fma(px[u], psc[FUSED ? u : 0], psh[FUSED ? u : 0]);
+        if (row < rend) Xs[xs_index(row - 4 * q.ks0, lane)] = (pvin && row < A.n) ? z : 0.0;
       }
     } else {
 #pragma unroll
@@ -211,18 +247,40 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       // latency; left to itself the compiler reads and waits inside every step).  Two
       // register sets in turn, so that no copies sit between the loads and the MFMAs;
       // the last step of a chunk prefetches itself again (the next chunk is not staged yet).
+      // (SPARSE: the group tests are wave-uniform bit tests of two scalar masks; a skipped group's
+      // operand registers keep stale values that its skipped MFMAs never read)
       auto ld = [&](int sidx, double &a, double (&bv)[B][MC]) {
         a = Xs[(size_t)(sidx - ks0) * 4 * TV + xo];
+        const bool lo_on = !SPARSE || ((act_lo >> sidx) & 1), hi_on = !SPARSE || ((act_hi >> sidx) & 1);
 #pragma unroll
-        for (int b = 0; b < B; ++b)
+        for (int b = 0; b < B; ++b) {
+          if (lo_on) {
 #pragma unroll
-          for (int mc = 0; mc < MC; ++mc) bv[b][mc] = ops[((size_t)(b * MC + mc) * A.nk + sidx) * 64 + lane];
+            for (int mc = 0; mc < SL; ++mc) bv[b][mc] = ops[((size_t)(b * MC + mc) * A.nk + sidx) * 64 + lane];
+          }
+#pragma unroll
+          for (int mc = SL; mc < SH; ++mc) bv[b][mc] = ops[((size_t)(b * MC + mc) * A.nk + sidx) * 64 + lane];
+          if (hi_on) {
+#pragma unroll
+            for (int mc = SH; mc < MC; ++mc) bv[b][mc] = ops[((size_t)(b * MC + mc) * A.nk + sidx) * 64 + lane];
+          }
+        }
       };
-      auto mm = [&](double a, double (&bv)[B][MC]) {
+      auto mm = [&](int sidx, double a, double (&bv)[B][MC]) {
+        const bool lo_on = !SPARSE || ((act_lo >> sidx) & 1), hi_on = !SPARSE || ((act_hi >> sidx) & 1);
 #pragma unroll
-        for (int b = 0; b < B; ++b)
+        for (int b = 0; b < B; ++b) {
+          if (lo_on) {
 #pragma unroll
-          for (int mc = 0; mc < MC; ++mc) D[b][mc] = mfma_f64(a, bv[b][mc], D[b][mc]);
+            for (int mc = 0; mc < SL; ++mc) D[b][mc] = mfma_f64(a, bv[b][mc], D[b][mc]);
+          }
+#pragma unroll
+          for (int mc = SL; mc < SH; ++mc) D[b][mc] = mfma_f64(a, bv[b][mc], D[b][mc]);
+          if (hi_on) {
+#pragma unroll
+            for (int mc = SH; mc < MC; ++mc) D[b][mc] = mfma_f64(a, bv[b][mc], D[b][mc]);
+          }
+        }
       };
       double a0, a1, b0[B][MC], b1[B][MC];
       ld(ks0, a0, b0);
@@ -230,12 +288,13 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       for (; s + 2 <= ks1; s += 2) {
         ld(s + 1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mm(a0, b0);
-        ld(min(s + 2, ks1 - 1), a0, b0);
+        mm(s, a0, b0);
+        const int s2 = min(s + 2, ks1 - 1);
+        ld(s2, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mm(a1, b1);
+        mm(s + 1, a1, b1);
       }
-      if (s < ks1) mm(a0, b0);
+      if (s < ks1) mm(s, a0, b0);
     }
     if (ks1 == A.nk) {
 #pragma unroll

@@ -463,7 +463,7 @@ namespace {
 struct GramFusedPlan {
   GramPlan g;
   FusedCells cells;
-  size_t o_sc, o_sh, o_cell, bytes;
+  size_t o_sc, o_sh, o_cell, o_act, o_tab, bytes;
 };
 
 bool gram_fused_plan(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo, const int32_t *cell_z,
@@ -471,7 +471,8 @@ bool gram_fused_plan(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo, c
   if (n <= 0 || !cell_lo || ncell <= 0 || ncell > FZ_MAXCELL || cell_lo[0] != 0 || cell_lo[ncell] != nz)
     return false;
   if ((size_t)n * TV * sizeof(double) > 160 * 1024) return false;        // statistics kernel's X tile
-  if (nz > 256) return false;          // the fused Gram keeps the source-row / cell tables in four registers apiece
+  if (nz > 256) return false;          // (one 64-bit activity mask per tile group: nk <= 64)
+  if (p >= ((int64_t)1 << 29)) return false;      // the fused Gram addresses voxels by a 32-bit byte offset
   if (!gram_plan(nz, m, items, p, true, pl.g)) return false;
   pl.cells.ncell = ncell;
   int steps = 0;
@@ -494,6 +495,8 @@ bool gram_fused_plan(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo, c
   pl.o_sc = take((size_t)items * ncell * p * sizeof(double));
   pl.o_sh = take((size_t)items * ncell * p * sizeof(double));
   pl.o_cell = take((size_t)nz * sizeof(int32_t));
+  pl.o_act = take(2 * sizeof(uint64_t));
+  pl.o_tab = take((size_t)items * nz * 2 * sizeof(int64_t));
   pl.bytes = off;
   return true;
 }
@@ -565,15 +568,35 @@ extern "C" int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   a.ncell = ncell;
   a.sc = sa.sc;
   a.sh = sa.sh;
-  int rc = PLSR_EUNSUPPORTED;
-  switch (g.MC) {
-    case 1: rc = launch_gram<1, 1, true>(a, g, st); break;
-    case 2: rc = launch_gram<2, 1, true>(a, g, st); break;
-    case 3: rc = launch_gram<3, 1, true>(a, g, st); break;
-    case 4: rc = launch_gram<4, 1, true>(a, g, st); break;
-    case 5: rc = launch_gram<5, 1, true>(a, g, st); break;
-    case 6: rc = launch_gram<6, 1, true>(a, g, st); break;
+  {
+    int64_t *tab = (int64_t *)(w + pl.o_tab);
+    const int64_t cnt = (int64_t)items * nz;
+    hipLaunchKernelGGL(gram_rowtab_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_src,
+                       (const int32_t *)rowcell, items, nz, ncell, ldx, p, tab);
+    a.rowtab = tab;
   }
+  // tile groups for an operator of two halves of m / 2 rows each (the split-half items): the low
+  // group ends where the second half's rows begin, the high group begins where the first half's end;
+  // what the groups may skip is read off the fragments (gram_activity_kernel), whatever the operator is
+  const int half = m / 2;
+  const int SL = g.MC > 1 ? half / 16 : 0, SH = g.MC > 1 ? (half + 15) / 16 : g.MC;
+  if (g.MC > 1) {
+    unsigned long long *act = (unsigned long long *)(w + pl.o_act);
+    if (hipMemsetAsync(act, 0, 2 * sizeof(uint64_t), st) != hipSuccess) return PLSR_ELAUNCH;
+    const int64_t total = (int64_t)items * g.MC * a.nk * 64;
+    const unsigned nb = (unsigned)std::min<int64_t>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(gram_activity_kernel, dim3(nb), dim3(256), 0, st, d_frag, total, g.MC, a.nk, SL, SH, act);
+    a.act = (const uint64_t *)act;
+  } else {
+    a.act = nullptr;
+  }
+  int rc = PLSR_EUNSUPPORTED;
+#define PLSR_GS(MCv, SLv, SHv) \
+  if (g.MC == MCv && SL == SLv && SH == SHv) rc = launch_gram<MCv, 1, true, SLv, SHv>(a, g, st);
+  if (g.MC == 1) rc = launch_gram<1, 1, true>(a, g, st);
+  PLSR_GS(2, 0, 1) PLSR_GS(2, 1, 1) PLSR_GS(3, 1, 1) PLSR_GS(3, 1, 2) PLSR_GS(4, 1, 2) PLSR_GS(4, 2, 2)
+  PLSR_GS(5, 2, 2) PLSR_GS(5, 2, 3) PLSR_GS(6, 2, 3) PLSR_GS(6, 3, 3)
+#undef PLSR_GS
   if (rc) return rc;
   const int64_t E = (int64_t)items * g.MM * g.MM;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
