@@ -184,13 +184,24 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       // rows past the wave's share or past n are fetched from a clamped row and never parked; voxels
       // past p (or a prefetch past the chunk) from a clamped voxel and parked as zeros (pvin)
       const uint32_t vo = (uint32_t)vc;                  // (p < 2^29: scalar base + 32-bit lane offset)
+      // table entries in batches ahead of the loads that need them (one at a time, each scalar
+      // load's round trip stood in front of its row's three vector loads)
+      constexpr int TB = 10;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int rc = min(rbeg + u, A.n - 1);
-        const i64x2 t = rowtab[rc];
-        px[u] = (A.X + t.x)[vo];
-        psc[u] = (A.sc + t.y)[vo];
-        psh[u] = (A.sh + t.y)[vo];
+      for (int u0 = 0; u0 < PF; u0 += TB) {
+        i64x2 t[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+          if (u0 + u < PF) t[u] = rowtab[min(rbeg + u0 + u, A.n - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+          if (u0 + u < PF) {
+            px[u0 + u] = (A.X + t[u].x)[vo];
+            psc[u0 + u] = (A.sc + t[u].y)[vo];
+            psh[u0 + u] = (A.sh + t[u].y)[vo];
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
       pvin = vin;
     } else {
@@ -209,11 +220,16 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       const int rpw = (4 * (ks1 - q.ks0) + WAVES - 1) / WAVES;
       const int rbeg = 4 * q.ks0 + wave * rpw;
       const int rend = min(4 * ks1, rbeg + rpw);
+      // the row's LDS slot: rows alternate between two lane offsets (xs_index swaps the 16-voxel
+      // blocks of odd rows), so two base pointers chosen once by the first row's parity and a
+      // compile-time row offset address all of them
+      const int r0 = rbeg - 4 * q.ks0;
+      double *even = Xs + xs_index(r0, lane), *odd = Xs + xs_index(r0 + 1, lane) - TV;
+      const int nlive = min(rend, A.n) - rbeg;             // rows beyond are padding: zeros
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
-        const int row = rbeg + u;
         const double z = fma(px[u], psc[FUSED ? u : 0], psh[FUSED ? u : 0]);
-        if (row < rend) Xs[xs_index(row - 4 * q.ks0, lane)] = (pvin && row < A.n) ? z : 0.0;
+        if (rbeg + u < rend) ((u & 1) ? odd : even)[u * TV] = (pvin && u < nlive) ? z : 0.0;
       }
     } else {
 #pragma unroll
