@@ -357,10 +357,12 @@ def main():
         # beside it: the kernel gets the same numbers with fewer flops, so that
         # rate can exceed the hardware peak and is not a utilisation figure.
         achieved = x_boot * per_launch / (bm * 1e-3) / 1e12
-        traffic = None
+        traffic = perm_traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and per_launch == NBOOT:
-            traffic = json.load(open(tpath)).get("boot_project_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("boot_project_bytes_per_launch")
+            perm_traffic = tj.get("perm_project_bytes_per_launch")
         line = {
             "metric": "resamples/sec (perm+boot), mct PLS X=60x200000",
             "value": head["value"], "unit": "resamples/s", "n_gpus": world, "steps": args.steps,
@@ -392,7 +394,12 @@ def main():
                 "unbatched_bytes_per_resample": 8 * n * p,
                 "unbatched_hbm_equivalent_TBps": 8 * n * p * per_launch / (bm * 1e-3) / 1e12,
                 "unbatched_hbm_equivalent_frac_of_8TBps": 8 * n * p * per_launch / (bm * 1e-3) / 8e12,
+                # algorithmic HBM bytes of a launch in its batched form: X once, the operator fragments,
+                # the moment sums (three p x k arrays) -- what `traffic` is to be held against
+                "algorithmic_bytes_per_launch": 8 * n * p + 8 * (per_launch * k) * ((n + 3) // 4 * 4) + 3 * 8 * p * k,
                 "perm_kernel": {"avg_launch_ms": pm, "launches": len(r["perm_ms"]),
+                                "traffic": perm_traffic if job["local_perm"] == NPERM else None,
+                                "algorithmic_bytes_per_launch": 8 * n * p + 8 * (job["local_perm"] * k) * ((n + 3) // 4 * 4),
                                 "achieved": x_perm * job["local_perm"] / (pm * 1e-3) / 1e12,
                                 "algorithmic_equivalent_tflops": f_perm * job["local_perm"] / (pm * 1e-3) / 1e12},
             },

@@ -37,6 +37,7 @@ if pmc:
     json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
     boot = [k for k in pmc if "project_boot_reg_kernel" in k and "false" in k] or \
            [k for k in pmc if "project_kernel<3, 1" in k]
+    perm = [k for k in pmc if "project_perm_reg_kernel" in k]
     if boot:
         b = pmc[boot[0]]
         fetch = b.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024
@@ -49,6 +50,10 @@ if pmc:
             "boot_project_fetch_bytes": fetch,
             "boot_project_write_bytes": write,
             "boot_project_bytes_per_launch": fetch + write,
+            **({"perm_kernel": perm[0],
+                "perm_project_bytes_per_launch": (pmc[perm[0]].get("FETCH_SIZE_KB_per_launch", 0.0) +
+                                                  pmc[perm[0]].get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024}
+               if perm else {}),
         }, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
         print("hbm_traffic.json", fetch + write)
 
