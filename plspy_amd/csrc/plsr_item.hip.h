@@ -28,6 +28,7 @@ struct LatentArgs {
 };
 
 constexpr int LV_T = 32;      // voxels per staged tile
+constexpr int XT_VLD = 34;    // K5x's padded LDS row (see latent_xt_kernel)
 constexpr int LV_LD = 33;     // padded LDS row: SQ_LDS_BANK_CONFLICT is 0 with 33; with 34 it was 45 % of the LDS cycles
 
 // MC = 16-row tiles of latent variables; NI = 16-row tiles of data rows per wave;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
   constexpr int NS = LV_T / 4;                    // k-steps per tile
   constexpr int RPP = WV * 4;                     // VS^T rows staged per pass (sixteen threads per row)
   constexpr int NV = (MC * 16 + RPP - 1) / RPP;
-  extern __shared__ __attribute__((aligned(16))) double smem[];   // two VS^T tiles [MC*16][LV_LD]
+  extern __shared__ __attribute__((aligned(16))) double smem[];   // two VS^T tiles [MC*16][XT_VLD]
   const bool want_nsq = A.nsq_part != nullptr;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
   const int64_t t_lo = (int64_t)chunk * A.tiles_per_chunk;
   const int64_t t_hi = min(nvt, t_lo + A.tiles_per_chunk);
   const int srow = tid >> 4, svox = (tid & 15) * 2;
-  constexpr int VT = MC * 16 * LV_LD;             // doubles per VS^T tile
+  constexpr int VT = MC * 16 * XT_VLD;             // doubles per VS^T tile
 
   f64x4 acc[MC];
   double nsq[MC];
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
     for (int q = 0; q < NV; ++q) {
       const int rr = q * RPP + srow;
       if (rr < MC * 16) {
-        Vs[rr * LV_LD + svox] = pv[q].x;
-        Vs[rr * LV_LD + svox + 1] = pv[q].y;
+        Vs[rr * XT_VLD + svox] = pv[q].x;
+        Vs[rr * XT_VLD + svox + 1] = pv[q].y;
       }
     }
   };
@@ -333,17 +334,27 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
       double a0[MC], a1[MC];
       auto lda = [&](int s, double (&a)[MC]) {
 #pragma unroll
-        for (int mc = 0; mc < MC; ++mc) a[mc] = Vs[(mc * 16 + col) * LV_LD + 4 * s + g];
+        for (int mc = 0; mc < MC; ++mc) a[mc] = Vs[(mc * 16 + col) * XT_VLD + 4 * s + g];
       };
       auto mm = [&](int s, double (&a)[MC]) {
 #pragma unroll
-        for (int mc = 0; mc < MC; ++mc) {
-          // column norms: k-step s is wave (s mod WV)'s share; voxels past p are clamped copies and do not count
-          if (want_nsq && s % WV == wave && (!edge || vt * LV_T + 4 * s + g < A.p)) nsq[mc] = fma(a[mc], a[mc], nsq[mc]);
-          acc[mc] = mfma_f64(a[mc], bx[s], acc[mc]);
-        }
+        for (int mc = 0; mc < MC; ++mc) acc[mc] = mfma_f64(a[mc], bx[s], acc[mc]);
         bx[s] = xn[(int64_t)s * 4 * XT_LD];
       };
+      // column norms: k-step s is wave (s mod WV)'s share, read once more from LDS in front of the MFMAs
+      // (taken from the MFMA operands under a per-step test of the wave index, it put a branch, an fp64
+      // FMA and two selects beside EVERY MFMA: 3.2 VALU instructions per MFMA in the counters);
+      // voxels past p are clamped copies and do not count
+      if (want_nsq) {
+        for (int s = wave; s < NS; s += WV) {
+          const bool in = !edge || vt * LV_T + 4 * s + g < A.p;
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) {
+            const double a = Vs[(mc * 16 + col) * XT_VLD + 4 * s + g];
+            nsq[mc] = fma(in ? a : 0.0, a, nsq[mc]);
+          }
+        }
+      }
       lda(0, a0);
 #pragma unroll
       for (int s = 0; s < NS; s += 2) {

@@ -208,7 +208,7 @@ extern "C" int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const do
   a.nsq_part = d_nsq ? a.Zt_part + pl.z_elems : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int MC = (k + 15) / 16, WV = (n + 15) / 16;
-  const size_t lds = std::max((size_t)2 * MC * 16 * LV_LD, (size_t)8 * MC * 16) * sizeof(double);
+  const size_t lds = std::max((size_t)2 * MC * 16 * XT_VLD, (size_t)8 * MC * 16) * sizeof(double);
   int rc = PLSR_EUNSUPPORTED;
 #define PLSR_LX(M, W)                                                                                              \
   if (MC == M && WV <= W && rc == PLSR_EUNSUPPORTED) {                                                             \
