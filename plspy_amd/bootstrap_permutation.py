@@ -639,7 +639,7 @@ class _ResampleTestPLS(ResampleTest):
             spread.add(LVc[a:z])
 
         res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch,
-                             beh=(yz, U), after_enqueue=self._finalize_early(niter, ref))
+                             beh=(yz, U), after_enqueue=self._finalize_early(niter, ref), need_nsq=False)
         std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = (spread.std() if nranks == 1 else np.std(LVcorr, axis=0)) * z    # :723-724

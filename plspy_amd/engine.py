@@ -577,7 +577,7 @@ class ProjectionEngine:
         return out
 
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
-                   on_batch=None, project_on=None, beh=None, after_enqueue=None):
+                   on_batch=None, project_on=None, beh=None, after_enqueue=None, need_nsq=True):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -594,6 +594,9 @@ class ProjectionEngine:
             latent scores (NumPy, (hi-lo, k, n) and (hi-lo, k)); it is called one
             batch late, while the device already works on the next batch, so the
             host's per-resample post-processing hides behind the kernels.
+        need_nsq=False: the caller does not use the column norms (behaviour PLS: its per-cell
+            z-score of the latent scores is scale invariant); the latent kernel then skips them
+            and nsq comes back as NaN.
         Returns dict(S1, S2 (p x k shifted moment sums), Zt (R, k, n) = (X VS_b)^T,
         nsq (R, k) = column norms^2 of VS_b)."""
         src = np.ascontiguousarray(src, dtype=np.int32)
@@ -604,6 +607,8 @@ class ProjectionEngine:
         S1, S2 = S12[0], S12[1]
         Zt = torch.empty((R, k, n), dtype=torch.float64, device=self.device)
         nsq = torch.empty((R, k), dtype=torch.float64, device=self.device)
+        if not need_nsq:
+            nsq.fill_(float("nan"))
         ncell = len(cell_z)
         per_item = (2 * ncell + k + 4) * self.p * 8 + 2 * k * nz * 8
         step = int(max(1, min(R, (self.work_limit // 2) // per_item)))
@@ -671,7 +676,7 @@ class ProjectionEngine:
                                            src_ranges=ranges if use_agg else None, pool=True)
             if not use_agg:
                 nsq[lo:hi] = rsq
-            self.latent_batch(vst, n, Zt[lo:hi], nsq[lo:hi] if use_agg else None)
+            self.latent_batch(vst, n, Zt[lo:hi], nsq[lo:hi] if use_agg and need_nsq else None)
             if on_batch is not None:
                 ev = torch.cuda.Event()
                 ev.record()
