@@ -364,3 +364,49 @@ def test_scale_cols_matches_numpy():
         Vd = torch.as_tensor(V).cuda()
         assert np.array_equal(eng.scale_cols(Vd, torch.as_tensor(s).cuda()).cpu().numpy(), V * s)
         assert np.array_equal(Vd.cpu().numpy(), V)
+
+
+@pytest.mark.gpu
+def test_fused_gram_block_sparse_operators():
+    """plsr_gram_fused with operators that are zero in whole (tile, k-step) blocks: the kernel skips the
+    k-steps of a tile group that gram_activity_kernel finds empty.  Shapes of every tile-group split
+    (m = 17 .. 96: one to six tiles), split-half-like halves, halves that overlap, an item that is dense
+    while the others are sparse (the masks are a union over the launch's items), an empty group."""
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(21)
+    for trial, m in enumerate([17, 32, 33, 40, 48, 50, 64, 65, 76, 80, 90, 96, 76, 96, 24]):
+        n, p = 40, int(rs.choice([130, 777, 2000]))
+        nz = int(rs.choice([40, 75, 100, 200]))
+        ncell = int(rs.randint(1, 7))
+        items = int(rs.randint(1, 6))
+        cell_lo = _cells(rs, nz, ncell)
+        zflags = rs.randint(0, 2, size=ncell)
+        X = rs.randn(n, p) + 1.0
+        src = rs.randint(0, n, size=(items, nz)).astype(np.int32)
+        rows = rs.randn(items, m, nz)
+        half, cut = m // 2, int(rs.randint(1, nz))
+        mode = trial % 5
+        if mode == 0:                               # two halves on disjoint rows (split-half)
+            rows[:, :half, cut:] = 0.0
+            rows[:, half:, :cut] = 0.0
+        elif mode == 1:                             # halves whose row ranges overlap
+            rows[:, :half, min(nz, cut + 9):] = 0.0
+            rows[:, half:, :max(0, cut - 9)] = 0.0
+        elif mode == 2:                             # the last item dense, the others sparse
+            rows[:-1, :half, cut:] = 0.0
+            rows[:-1, half:, :cut] = 0.0
+        elif mode == 3:                             # the first half does nothing at all
+            rows[:, :half] = 0.0
+        else:                                       # scattered zero blocks of four rows
+            for s0 in range(0, nz, 4):
+                if rs.rand() < 0.5:
+                    rows[:, :half, s0:s0 + 4] = 0.0
+                if rs.rand() < 0.5:
+                    rows[:, half:, s0:s0 + 4] = 0.0
+        eng = ProjectionEngine(X)
+        tag = f"trial {trial}: m={m} nz={nz} cells={ncell} items={items} p={p} mode={mode}"
+        G = eng.gram_phase(rows, gather=dict(src=src, cell_lo=cell_lo, cell_z=zflags)).cpu().numpy()
+        M = np.einsum("bji,biv->bjv", rows, _zscore_items(X, src, cell_lo, zflags))
+        want = np.einsum("bjv,blv->bjl", M, M)
+        np.testing.assert_allclose(G[:, :m, :m], want, rtol=1e-9, atol=1e-10 * max(np.abs(want).max(), 1e-300),
+                                   err_msg=tag)
