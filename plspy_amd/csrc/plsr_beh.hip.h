@@ -132,7 +132,12 @@ struct BehArgs {
 #endif
 };
 
-template <int CSMAX, int NCMAX, int BP>
+// EXACT: the launch has exactly NCMAX cells of CSMAX k-steps and three tiles of latent variables (the
+// BASELINE shape: six cells of twenty rows, k = 48), so every guard on the step counts is true at
+// compile time -- the guards cost a compare and a branch beside each MFMA (3.5 SALU instructions per
+// MFMA in the counters of the generic instance).  The basic-block boundaries the guards gave the
+// scheduler are kept as scheduling barriers (without them it hoists the operand loads and spills).
+template <int CSMAX, int NCMAX, int BP, bool EXACT = false>
 __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
   constexpr int NF = CSMAX * NCMAX;                // fragments of X in registers
   constexpr int IP = 16 / BP;                      // items per stage-1 tile
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
   const int it_lo = blockIdx.y * A.per;
   const int it_hi = min(A.items, it_lo + A.per);
   if (it_lo >= it_hi) return;
-  const int ncell = A.ncell, cs = A.cs, MC = A.MC;
+  const int ncell = EXACT ? NCMAX : A.ncell, cs = EXACT ? CSMAX : A.cs, MC = EXACT ? 3 : A.MC;
   const int unit = ncell * cs * 64;                // doubles of a group's stage-1 fragments
   const int unit_p = (unit + 511) / 512 * 512;     // ... padded to whole 16-byte pieces of 256 threads
   // LDS: [U2: ncell * QB * MC * 64][two stage-1 units][scale: waves x ncell x 64]
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
     const double *mp = A.mfrag + ((size_t)sg * ncell * cs) * 64 + lane;
     uint32_t susp = 0;
     int ncell_ = ncell, cs_ = cs;
-    asm volatile("" : "+s"(ncell_), "+s"(cs_));          // (see the group loop)
+    if (!EXACT) asm volatile("" : "+s"(ncell_), "+s"(cs_));          // (see the group loop)
     // the multiplicity fragments of cell c + 1 are fetched while cell c is summed (an L2 round trip
     // per cell was the larger part of this phase)
     double mfn[CSMAX];
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
               s2a = mfma4_f64(m, xv * xv, s2a);
             }
           }
+          if (EXACT) __builtin_amdgcn_sched_barrier(0);
         }
         const double s1c = s1a + s1b, s2c = s2a + s2b;
         const double cnt = ctab[2 * c];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
     // comparisons being hoisted out of it as one 64-bit mask per guard -- two dozen SGPR pairs that
     // spilled into VGPR lanes and from there into scratch
     int ncell_ = ncell, cs_ = cs, MC_ = MC;
-    asm volatile("" : "+s"(ncell_), "+s"(cs_), "+s"(MC_));
+    if (!EXACT) asm volatile("" : "+s"(ncell_), "+s"(cs_), "+s"(MC_));
     const double *cur = bufs + par * unit_p + lane;
     d2 *nxt = (d2 *)(bufs + (par ^ 1) * unit_p) + tid;
     gsrc += unit / 2;                              // next group's pieces (the stream is padded by one unit)
@@ -354,6 +360,7 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
 #pragma unroll
         for (int t = 0; t < CSMAX; ++t) {
           if (t < cs_) r1 = mfma_f64(fan[t], x[c * CSMAX + t], r1);
+          if (EXACT) __builtin_amdgcn_sched_barrier(0);
           fan[t] = a1p[(size_t)(t < cs_ ? t : 0) * 64];           // slot t: refilled right after its use (past the last cell: unused)
         }
 #pragma unroll
@@ -361,10 +368,13 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
           const int ii = (4 * r) / BP, qq = ((4 * r) % BP) / 4;
           const double bop = r1[r] * scl[ii];
 #pragma unroll
-          for (int mc = 0; mc < MCM; ++mc)
+          for (int mc = 0; mc < MCM; ++mc) {
             if (mc < MC_) acc2[ii][mc] = mfma_f64(uf[qq][mc], bop, acc2[ii][mc]);
+            if (EXACT) __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
+      if (EXACT) __builtin_amdgcn_sched_barrier(0);
     }
 
     // The scales of the NEXT four items are computed here, ahead of this group's stores: a wave's

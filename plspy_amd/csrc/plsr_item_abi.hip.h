@@ -965,6 +965,8 @@ int run_beh(const BehArgs &a, const BehPlan &pl, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)pl.nwg, (unsigned)pl.nsplit), dim3(BH_WAVES * 64), pl.lds, st, a);
     return launch_ok();
   };
+  if (CSMAX == 5 && NCMAX == 6 && pl.BP == 8 && a.ncell == NCMAX && a.cs == CSMAX && a.MC == 3 && !getenv("PLSR_BEH_GENERIC"))
+    return launch(item_beh_kernel<5, 6, 8, true>);          // every step live: the instance without guards
   return pl.BP == 8 ? launch(item_beh_kernel<CSMAX, NCMAX, 8>) : launch(item_beh_kernel<CSMAX, NCMAX, 16>);
 }
 }  // namespace
