@@ -45,22 +45,28 @@ struct GramArgs {
   // block-sparse operators (template SL / SH): bit s of act[0] -- some item's operator is non-zero in
   // k-step s of a tile below SL; act[1] -- of a tile from SH on (gram_activity_kernel)
   const uint64_t *act;
-  // FUSED: per (item, row) the element offsets of the row's source row in X and of its cell's scale /
-  // shift rows in sc / sh (gram_rowtab_kernel): [items][n] pairs, read through the scalar cache
+  // FUSED: per (item, row) the addresses of the row's source row in X and of its cell's rows in sc / sh
+  // (gram_rowtab_kernel): [items][4 nk + GRAM_PF] entries of four words, read through the scalar cache
   const int64_t *rowtab;
 };
 
-// rowtab[item][row] = { src[item][row] * ldx,  (item * ncell + rowcell[row]) * p }
+constexpr int GRAM_PF = 20;   // rows of X a thread parks in registers per K-chunk (ks <= GRAM_PF)
+
+// rowtab[item][row] = { &X[src[item][row]][0], &sc[item][cell(row)][0], &sh[item][cell(row)][0], 0 } for row <
+// 4 nk + GRAM_PF, rows from n on repeating row n - 1: a wave reads entries rbeg .. rbeg + PF - 1 without a clamp
 __global__ __launch_bounds__(256) void gram_rowtab_kernel(const int32_t *src, const int32_t *rowcell, int items, int n,
-                                                          int ncell, int64_t ldx, int64_t p, int64_t *tab) {
+                                                          int ntr, int ncell, const double *X, int64_t ldx,
+                                                          const double *sc, const double *sh, int64_t p, int64_t *tab) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)items * n) return;
-  const int item = (int)(e / n), row = (int)(e % n);
-  tab[2 * e] = (int64_t)src[e] * ldx;
-  tab[2 * e + 1] = ((int64_t)item * ncell + rowcell[row]) * p;
+  if (e >= (int64_t)items * ntr) return;
+  const int item = (int)(e / ntr), row = min((int)(e % ntr), n - 1);
+  const int64_t cell_row = ((int64_t)item * ncell + rowcell[row]) * p;
+  tab[4 * e] = (int64_t)(uintptr_t)(X + (int64_t)src[(int64_t)item * n + row] * ldx);
+  tab[4 * e + 1] = (int64_t)(uintptr_t)(sc + cell_row);
+  tab[4 * e + 2] = (int64_t)(uintptr_t)(sh + cell_row);
+  tab[4 * e + 3] = 0;
 }
 
-constexpr int GRAM_PF = 20;   // rows of X a thread parks in registers per K-chunk (ks <= GRAM_PF)
 // ... except for six-tile items that stage their own gathered / z-scored rows (m = 81..96, e.g.
 // behaviour split-half with k = 48): 21 Gram tiles + three parked values per row spilled
 // 124 bytes per lane at 20 rows (16 at 10); 8 rows fit
@@ -170,9 +176,10 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
   // cell tables in vector registers and picked entries with v_readlane: ninety-odd instructions per
   // row with the 64-bit address arithmetic -- 4 700 per voxel tile and wave, more issue time than the
   // tile's MFMAs take.)
-  typedef long long i64x2 __attribute__((ext_vector_type(2)));
-  const __attribute__((address_space(4))) i64x2 *rowtab =
-      (const __attribute__((address_space(4))) i64x2 *)(uintptr_t)(A.rowtab + (FUSED ? (int64_t)item0 * A.n * 2 : 0));
+  typedef long long i64x4 __attribute__((ext_vector_type(4)));
+  const int ntr = 4 * A.nk + GRAM_PF;
+  const __attribute__((address_space(4))) i64x4 *rowtab =
+      (const __attribute__((address_space(4))) i64x4 *)(uintptr_t)(A.rowtab + (FUSED ? (int64_t)item0 * ntr * 4 : 0));
   auto fetch = [&](Pos q) {
     const int ks1 = min(A.nk, q.ks0 + A.ks);
     const int64_t v = q.vt * TV + lane;
@@ -186,20 +193,20 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramArgs A) {
       const uint32_t vo = (uint32_t)vc;                  // (p < 2^29: scalar base + 32-bit lane offset)
       // table entries in batches ahead of the loads that need them (one at a time, each scalar
       // load's round trip stood in front of its row's three vector loads)
-      constexpr int TB = 10;
+      constexpr int TB = 5;
 #pragma unroll
       for (int u0 = 0; u0 < PF; u0 += TB) {
-        i64x2 t[TB];
+        i64x4 t[TB];
 #pragma unroll
         for (int u = 0; u < TB; ++u)
-          if (u0 + u < PF) t[u] = rowtab[min(rbeg + u0 + u, A.n - 1)];
+          if (u0 + u < PF) t[u] = rowtab[rbeg + u0 + u];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < TB; ++u)
           if (u0 + u < PF) {
-            px[u0 + u] = (A.X + t[u].x)[vo];
-            psc[u0 + u] = (A.sc + t[u].y)[vo];
-            psh[u0 + u] = (A.sh + t[u].y)[vo];
+            px[u0 + u] = ((const double *)(uintptr_t)t[u].x)[vo];
+            psc[u0 + u] = ((const double *)(uintptr_t)t[u].y)[vo];
+            psh[u0 + u] = ((const double *)(uintptr_t)t[u].z)[vo];
           }
         __builtin_amdgcn_sched_barrier(0);
       }

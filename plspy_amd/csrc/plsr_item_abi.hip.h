@@ -496,7 +496,7 @@ bool gram_fused_plan(int32_t n, int32_t nz, int32_t m, const int32_t *cell_lo, c
   pl.o_sh = take((size_t)items * ncell * p * sizeof(double));
   pl.o_cell = take((size_t)nz * sizeof(int32_t));
   pl.o_act = take(2 * sizeof(uint64_t));
-  pl.o_tab = take((size_t)items * nz * 2 * sizeof(int64_t));
+  pl.o_tab = take((size_t)items * (4 * ((nz + 3) / 4) + GRAM_PF) * 4 * sizeof(int64_t));
   pl.bytes = off;
   return true;
 }
@@ -570,9 +570,11 @@ extern "C" int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_
   a.sh = sa.sh;
   {
     int64_t *tab = (int64_t *)(w + pl.o_tab);
-    const int64_t cnt = (int64_t)items * nz;
+    const int ntr = 4 * a.nk + GRAM_PF;
+    const int64_t cnt = (int64_t)items * ntr;
     hipLaunchKernelGGL(gram_rowtab_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_src,
-                       (const int32_t *)rowcell, items, nz, ncell, ldx, p, tab);
+                       (const int32_t *)rowcell, items, nz, ntr, ncell, d_X, ldx, (const double *)sa.sc,
+                       (const double *)sa.sh, p, tab);
     a.rowtab = tab;
   }
   // tile groups for an operator of two halves of m / 2 rows each (the split-half items): the low
