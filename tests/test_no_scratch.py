@@ -20,7 +20,7 @@ def test_every_kernel_instance_is_free_of_scratch(tmp_path):
     assert len(rows) > 100, "remarks not parsed"
     names = " ".join(r["name"] for r in rows)
     for must in ("project_boot_reg_kernel<15, false, 2>", "project_kernel<4, 1, 4>", "project_kernel<6, 1, 0>",
-                 "gram_kernel<6, 1, true>", "item_fused2_kernel", "latent_kernel<3, 1, 1, 8>"):
+                 "gram_kernel<6, 1, true, 3, 3>", "gram_kernel<5, 1, true, 2, 3>", "item_beh_kernel<5, 6, 8, true>", "item_fused2_kernel", "latent_kernel<3, 1, 1, 8>"):
         assert must in names, f"{must} not among the compiled instances"
     bad = [(r["name"], r["scratch"]) for r in rows if r["scratch"] != 0]
     assert not bad, f"kernel instances with scratch: {bad}"
