@@ -390,6 +390,33 @@ int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     size_t work_bytes, void *stream);
 
 /*
+ * K2s: the per-split Grams of behaviour / multiblock PLS in two stages (plsr_split.hip.h), the fast path of
+ * the split-half tests (split_half_resampling.py:119-197, :266-383, :548-683, :687-802; the cross-blocks of
+ * class_functions.py:185-247 and :454-516 are never stored).  An item's rows of X are grouped in CELL SLOTS
+ * (the half's group x condition cells): the first nbq slots carry b behaviour rows each (the cell's rows of
+ * X z-scored per voxel, times the cell's rows of Y z-scored per column), the others only feed the task rows,
+ * which are linear in the cells' sums:  T[j] = sum_q d_Wc[j][q] * (sum of the rows of slot q).
+ *   d_xsrc, d_ysrc : [items][nz] int32, rows of X / of d_Y per (slot, row), slots concatenated (d_ysrc is
+ *                    read for the first nbq slots only)
+ *   cell_rows      : HOST [nq] rows per slot (sum = nz)
+ *   d_Y [.][b], b <= 8;  d_Wc [ktask][nq] (ktask <= 16) or null
+ *   row_cell / row_sub : HOST [m], what row l of the item's stacked cross-block is: behaviour row row_sub[l]
+ *                    of slot row_cell[l] >= 0, or (row_cell[l] < 0) task row row_sub[l]
+ *   normalise      : G_ij / (sqrt(G_ii) sqrt(G_jj)) -- the multiblock row normalisation
+ *                    (class_functions.py:503-505) applied to the Gram; rows of norm 0 give 0
+ *   d_G            : [items][mm][mm], mm = 16 ceil(m / 16), rows / columns past m are 0
+ * The workspace query returns 0 for shapes the kernel's instances do not serve (b > 8, cells of more than 12
+ * / 20 rows, more than 10-16 cells, X of 4 GiB or more, p < 16): plsr_gram_fused serves those.
+ */
+size_t plsr_split_gram_workspace_bytes(int32_t n, int64_t ldx, int64_t p, int32_t b, const int32_t *cell_rows,
+                                       int32_t nq, int32_t nbq, int32_t ktask, int32_t m, int32_t items);
+int plsr_split_gram(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_xsrc,
+                    const int32_t *d_ysrc, int32_t nz, const double *d_Y, int32_t b, const int32_t *cell_rows,
+                    int32_t nq, int32_t nbq, const double *d_Wc, int32_t ktask, const int32_t *row_cell,
+                    const int32_t *row_sub, int32_t m, int32_t normalise, int32_t items, double *d_G,
+                    void *d_work, size_t work_bytes, void *stream);
+
+/*
  * ---- F4: the upstream feed, X built on the device ---------------------------------
  * plspy/io/io.py:427-460 (apply_mask_matrices: `m[np.broadcast_to(mask, m.shape)]` -- for every
  * time point the voxels the mask selects, in C order) and :680-698 (concat_flatten_all_groups:

@@ -805,3 +805,4 @@ extern "C" int plsr_apply_rows(const double *d_X, int64_t ldx, int64_t p, int32_
 // K4 / K5 entry points (same translation unit: the shared kernels in
 // plsr_project.hip.h are defined once)
 #include "plsr_item_abi.hip.h"
+#include "plsr_split_abi.hip.h"

@@ -1,0 +1,368 @@
+// K2s: per-split Grams of behaviour / multiblock PLS in two stages, one wave per (item, voxel chunk).
+//
+// A split-half item (split_half_resampling.py:119-197, :266-383, :548-683, :687-802) stacks the two
+// halves' cross-blocks M = [M1; M2]; everything the reference derives from the halves' SVDs follows from
+// G = M M^T (k x k blocks G11, G12, G22).  A half's cross-block is, per (group, condition) CELL of the
+// half's rows (class_functions.py:185-247, :454-516):
+//
+//   behaviour rows   R_c[beh, v] = sum_{r in c} Yz_c[r, beh] (X[r, v] - mean_c(v)) / sqrt(ss_c(v))
+//                                = sc_c(v) * sum_{r in c} Yz_c[r, beh] X[r, v]         (Yz_c sums to 0 over c)
+//   task rows        T[j, v]     = sum_c Wc[j, c] * S_c(v),   S_c(v) = sum_{r in c} X[r, v]
+//                                  (the mean-centring operator is constant inside a cell)
+//
+// so the item needs, per voxel: the cells' sums and centred sums of squares (two-pass, from the rows in
+// registers), one small product per behaviour cell on the RAW rows, a scale of its accumulator, one tiny
+// product for the task rows, and the Gram of the lot.  The fused kernel of round 2
+// (gram_kernel<.., FUSED>, plsr_gram.hip.h) staged every row z-scored through LDS and multiplied the
+// stacked dense operator (200 rows x 76 at config 4): 150 + 60 MFMAs per 16 voxels behind sixty vector
+// loads, twenty parked rows and two barriers per K-chunk -- matrix pipe 30 % busy.  Here:
+//
+//   * orientation D[voxel][operator row]: the gathered rows of X are the MFMA A operand, loaded
+//     STRAIGHT from global memory into that layout (lane (voxel, kk) reads row src[4 s + kk] of its
+//     voxel: one 512-byte access of four 128-byte row segments, scalar base + one 32-bit lane offset
+//     per slot, kept in registers for the whole chunk) -- no LDS staging, no barrier, no gather kernel;
+//   * a ring of one register pair per (cell, k-step) slot: slot j of tile t + 1 is requested right
+//     after slot j of tile t has been consumed, so every load has a whole tile's MFMAs to arrive;
+//   * statistics on the same registers: the lane's own rows are summed on the VALU, the four kk lanes
+//     of a voxel are summed by v_mfma_f64_4x4x4 (A = ones: every lane gets its voxel's cell sum; A =
+//     one-hot: lane (i, voxel) collects cell 4 g + i) -- which is also the layout of the task product's
+//     A operand and, through a 16-entry LDS patch, of the accumulators' scale;
+//   * the scaled accumulators are, unchanged, both operands of the Gram MFMAs (as in gram_kernel);
+//   * 24 + 3 + 60 MFMAs per 16 voxels at config 4 (k = 38) instead of 210.
+//
+// One wave = one workgroup = (item, voxel chunk); G lives in registers for the chunk (15 tiles = 120
+// VGPRs at five row tiles) and leaves as one partial per chunk; split_reduce_kernel sums the chunks in
+// fixed order, undoes the kernel's row order and applies the multiblock row normalisation
+// (class_functions.py:503-505 on the Gram: G_ij / (|row_i| |row_j|)).  Workgroup ids go round the
+// eight XCDs, and id mod 8 picks the voxel range: the waves of an XCD sweep the same eighth of X, which
+// then crosses the fabric once per XCD instead of once per item.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plsr_agg.hip.h"
+
+namespace plsr {
+
+constexpr int SG_MAXQ = 20;          // cell slots of an item (behaviour cells first, then task-only cells)
+constexpr int SG_BP = 8;             // behaviour rows per cell in a 16-column tile (b <= 8)
+constexpr int SG_IP = 16 / SG_BP;    // cells per tile
+
+struct SplitMetaArgs {
+  const int32_t *xsrc, *ysrc;        // [items][nz] rows of X / of Y per (cell, row), cells concatenated in slot order
+  const double *Y;                   // [ny][b]
+  int32_t b, items, nz, nq, nbq, cs; // nq cell slots of cs k-steps; the first nbq carry behaviour rows
+  int32_t cell_lo[SG_MAXQ + 1];
+  int64_t ldx_bytes;
+  uint32_t *roff;                    // [items][nq * cs][4] byte offset of the slot's source row in X
+  double *bfrag;                     // [items][nbq * cs][64] stage-1 B fragments (Yz, zero padded)
+};
+
+// roff: slot (q, s), lane group kk -> row xsrc[cell_lo[q] + 4 s + kk] (rows past the cell repeat its first
+// row: loaded, never used).  bfrag: lane (col, kk) of slot (q, s) = Yz_q[4 s + kk][col - (q % IP) BP] with
+// Yz_q the cell's rows of Y z-scored per column (ddof 0, / sqrt(n_c), constant columns -> 0:
+// class_functions.py:229-238).
+__global__ __launch_bounds__(256) void split_meta_kernel(SplitMetaArgs A) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n1 = (int64_t)A.items * A.nq * A.cs * 4;
+  const int64_t n2 = (int64_t)A.items * A.nbq * A.cs * 64;
+  if (e < n1) {
+    const int kk = (int)(e & 3);
+    int64_t t = e >> 2;
+    const int s = (int)(t % A.cs);
+    t /= A.cs;
+    const int q = (int)(t % A.nq);
+    const int item = (int)(t / A.nq);
+    const int nc = A.cell_lo[q + 1] - A.cell_lo[q];
+    const int r = 4 * s + kk;
+    const int32_t row = nc > 0 ? A.xsrc[(int64_t)item * A.nz + A.cell_lo[q] + (r < nc ? r : 0)] : 0;
+    A.roff[e] = (uint32_t)((int64_t)row * A.ldx_bytes);
+  } else if (e - n1 < n2) {
+    const int64_t f = e - n1;
+    const int lane = (int)(f & 63);
+    int64_t t = f >> 6;
+    const int s = (int)(t % A.cs);
+    t /= A.cs;
+    const int q = (int)(t % A.nbq);
+    const int item = (int)(t / A.nbq);
+    const int col = lane & 15, kk = lane >> 4;
+    const int beh = col - (q % SG_IP) * SG_BP;
+    const int lo = A.cell_lo[q], nc = A.cell_lo[q + 1] - lo;
+    const int r = 4 * s + kk;
+    double z = 0.0;
+    if (beh >= 0 && beh < A.b && beh < SG_BP && r < nc) {
+      const int32_t *ys = A.ysrc + (int64_t)item * A.nz + lo;
+      double mu = 0.0;
+      for (int i = 0; i < nc; ++i) mu += A.Y[(int64_t)ys[i] * A.b + beh];
+      mu /= (double)nc;
+      double ss = 0.0;
+      for (int i = 0; i < nc; ++i) {
+        const double d = A.Y[(int64_t)ys[i] * A.b + beh] - mu;
+        ss = fma(d, d, ss);
+      }
+      const double sd = sqrt(ss / (double)nc);
+      if (sd > 2.220446049250313e-16 * fabs(mu)) z = (A.Y[(int64_t)ys[r] * A.b + beh] - mu) / sd / sqrt((double)nc);
+    }
+    A.bfrag[f] = z;
+  }
+}
+
+// task coefficients as B fragments: group g4 of four cells, lane (col = task row j, kk) = Wc[j][4 g4 + kk]
+__global__ __launch_bounds__(64) void split_wfrag_kernel(const double *Wc, int ktask, int nq, double *wfrag) {
+  const int g4 = blockIdx.x, lane = threadIdx.x;
+  const int j = lane & 15, c = 4 * g4 + (lane >> 4);
+  wfrag[g4 * 64 + lane] = (j < ktask && c < nq) ? Wc[j * nq + c] : 0.0;
+}
+
+struct SplitArgs {
+  const double *X;
+  int64_t p;
+  int32_t items, nq, nbq, cs;          // run-time counts (the template's are maxima unless EXACT)
+  int32_t nrow[SG_MAXQ];               // rows of every cell slot (0: empty slot)
+  double rn[SG_MAXQ];                  // 1 / rows (0 for an empty slot)
+  const uint32_t *roff;                // [items][nq * cs][4]
+  const double *bfrag;                 // [items][nbq * cs][64]
+  const double *wfrag;                 // [ceil(nq / 4)][64] or null
+  int32_t nx, csub;                    // voxel ranges per item: nx (<= 8, the XCDs) x csub
+  int64_t ntile;                       // 16-voxel tiles
+  double *Gp;                          // [items][nx * csub][NG][4][64]
+};
+
+
+// NTB behaviour tiles (two cells each), NTO pairs of task-only cells, NTT (0 / 1) task tile, CS k-steps per
+// cell.  EXACT: the launch has exactly these counts and every cell has more than 4 (CS - 1) rows, so all
+// guards fold and only a cell's last k-step is masked.
+template <int NTB, int NTO, int NTT, int CS, bool EXACT>
+__global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
+  constexpr int IP = SG_IP;
+  constexpr int NP = NTB + NTO;                    // cell pairs
+  constexpr int NQ = NP * IP;                      // cell slots
+  constexpr int NS = NQ * CS;                      // ring slots
+  constexpr int MC = NTB + NTT;                    // row tiles of the Gram
+  constexpr int NG = MC * (MC + 1) / 2;
+  constexpr int NG4 = (NQ + 3) / 4;
+  static_assert(NQ <= SG_MAXQ && NS <= 63, "cell slots / outstanding loads");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int col = lane & 15, kk = lane >> 4;
+  const int nq = EXACT ? NQ : A.nq, nbq = EXACT ? NTB * IP : A.nbq, cs = EXACT ? CS : A.cs;
+
+  // ---- which (item, voxel range) ----
+  const int64_t wg = blockIdx.x;
+  const int xcd = (int)(wg % A.nx);
+  const int64_t rest = wg / A.nx;
+  const int item = (int)(rest % A.items);
+  const int sub = (int)(rest / A.items);
+  const int64_t per_x = (A.ntile + A.nx - 1) / A.nx;
+  const int64_t per_s = (per_x + A.csub - 1) / A.csub;
+  const int64_t x_lo = (int64_t)xcd * per_x, x_hi = min(A.ntile, x_lo + per_x);
+  const int64_t t_lo = min(x_hi, x_lo + (int64_t)sub * per_s), t_hi = min(x_hi, t_lo + per_s);
+  const int chunk = xcd * A.csub + sub;
+
+  // ---- LDS: this item's stage-1 fragments, then the scale patch ----
+  double *bf = smem;                                // [nbq * cs][64]
+  double *st = smem + (size_t)nbq * cs * 64;        // [NQ][16]
+  {
+    const double *src = A.bfrag + (size_t)item * nbq * cs * 64;
+    for (int e = 0; e < nbq * cs; ++e) bf[e * 64 + lane] = src[e * 64 + lane];
+  }
+  // ---- per-slot row offsets (+ this lane's voxel): LDS, [slot][lane] -- sixty of them in registers beside
+  // the ring's sixty pairs and the Gram's 120 accumulators left the config-4 instance 80 bytes of scratch ----
+  uint32_t *rl = (uint32_t *)(st + (size_t)NG4 * 4 * 16);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      const bool live = EXACT || (q < nq && s < cs);
+      rl[(q * CS + s) * 64 + lane] =
+          A.roff[((size_t)item * nq * cs + (live ? q * cs + s : 0)) * 4 + kk] + (uint32_t)col * 8u;
+    }
+  asm volatile("" ::: "memory");
+  // per-lane constants of the finalising layout: lane (i = kk, voxel = col) owns cell 4 g4 + i
+  double cntl[NG4], rnl[NG4];
+#pragma unroll
+  for (int g4 = 0; g4 < NG4; ++g4) {
+    const int q = 4 * g4 + kk;
+    const int nr = q < NQ ? A.nrow[q] : 0;
+    cntl[g4] = (double)nr;
+    rnl[g4] = nr > 0 ? 1.0 / (double)nr : 0.0;
+  }
+  double wf[NTT ? NG4 : 1];
+  if (NTT) {
+#pragma unroll
+    for (int g4 = 0; g4 < NG4; ++g4) wf[g4] = A.wfrag[g4 * 64 + lane];
+  }
+  const double one = 1.0;
+  double hot[4], khot[4];          // one-hot A operands of the 4x4x4 MFMA; this lane's kk as a 0 / 1 weight
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    hot[u] = (lane & 3) == u ? 1.0 : 0.0;
+    khot[u] = kk == u ? 1.0 : 0.0;
+  }
+
+  f64x4 G[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) G[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  // tile t covers voxels [16 t, 16 t + 16); the last one is read from p - 16 and masks what tile t - 1 had
+  auto tile_v0 = [&](int64_t t) { return min(16 * t, A.p - 16); };
+  const char *Xb = (const char *)A.X;
+  double xr[NS];
+  if (t_lo < t_hi) {
+    const char *b0 = Xb + tile_v0(t_lo) * 8;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) xr[j] = *(const double *)(b0 + rl[j * 64 + lane]);
+  }
+  asm volatile("" ::: "memory");
+
+  for (int64_t tile = t_lo; tile < t_hi; ++tile) {
+    const int64_t v0 = tile_v0(tile);
+    const bool vvalid = v0 + col >= 16 * tile;
+    const char *bn = Xb + tile_v0(min(tile + 1, t_hi - 1)) * 8;     // next tile's rows (the last tile re-reads itself)
+    f64x4 D[MC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m) D[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+#pragma unroll
+    for (int g4 = 0; g4 < NG4; ++g4) {
+      double totc[4] = {0.0, 0.0, 0.0, 0.0};
+      double ssq = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = 4 * g4 + u;
+        if (q < NQ && (EXACT || q < nq)) {
+          const int t = q / IP;
+          const int nr = A.nrow[q];
+          double x[CS], xm[CS];
+#pragma unroll
+          for (int s = 0; s < CS; ++s) {
+            x[s] = xr[q * CS + s];
+            xr[q * CS + s] = *(const double *)(bn + rl[(q * CS + s) * 64 + lane]);   // slot refilled right after its use
+          }
+          // the lane's own rows of the cell (4 s + kk < n_c), summed; then over the four kk lanes
+          double s1p = 0.0;
+#pragma unroll
+          for (int s = 0; s < CS; ++s) {
+            const bool ok = (EXACT && s < CS - 1) || 4 * s + kk < nr;
+            xm[s] = ok ? x[s] : 0.0;
+            s1p += xm[s];
+          }
+          const double tot = mfma4_f64(one, s1p, 0.0);
+          totc[u] = tot;
+          if (t < NTB && (EXACT || q < nbq)) {
+            const double mean = tot * A.rn[q];
+            double ssp = 0.0;
+#pragma unroll
+            for (int s = 0; s < CS; ++s) {
+              const bool ok = (EXACT && s < CS - 1) || 4 * s + kk < nr;
+              const double d = ok ? x[s] - mean : 0.0;
+              ssp = fma(d, d, ssp);
+            }
+            ssq = mfma4_f64(hot[u], ssp, ssq);
+#pragma unroll
+            for (int s = 0; s < CS; ++s)
+              if (EXACT || s < cs) D[t] = mfma_f64(x[s], bf[(q * cs + s) * 64 + lane], D[t]);
+          }
+        }
+      }
+      // ---- the group's four cells: lane (i = kk, voxel = col) finalises cell 4 g4 + i ----
+      // (a weighted sum with 0 / 1 weights: nested selects on values that live in accumulator registers
+      // became divergent branches)
+      const double s1sel = fma(totc[0], khot[0], fma(totc[1], khot[1], fma(totc[2], khot[2], totc[3] * khot[3])));
+      if (4 * g4 < NTB * IP) {
+        const double mean = s1sel * rnl[g4];
+        const double em = 2.220446049250313e-16 * fabs(mean);
+        const bool dead = !(ssq > cntl[g4] * em * em) || !vvalid;
+        st[(4 * g4 + kk) * 16 + (col & 3) * 4 + (col >> 2)] = dead ? 0.0 : rsqrt(ssq);
+      }
+      if (NTT) D[MC - 1] = mfma_f64(vvalid ? s1sel : 0.0, wf[g4], D[MC - 1]);
+      asm volatile("" ::: "memory");
+      // ---- scale the group's behaviour tiles: accumulator lane (col, kk), register r = voxel kk + 4 r ----
+#pragma unroll
+      for (int tt = 0; tt < 4 / IP; ++tt) {
+        const int t = g4 * (4 / IP) + tt;
+        if (t < NTB && (EXACT || t * IP < nbq)) {
+          const double *sp = st + (t * IP + (col >> 3)) * 16 + kk * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) D[t][r] *= sp[r];
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+
+    // ---- Gram of the tile's rows ----
+    {
+      int idx = 0;
+#pragma unroll
+      for (int m1 = 0; m1 < MC; ++m1)
+#pragma unroll
+        for (int m2 = m1; m2 < MC; ++m2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) G[idx] = mfma_f64(D[m1][r], D[m2][r], G[idx]);
+          ++idx;
+        }
+    }
+  }
+
+  double *out = A.Gp + ((size_t)item * A.nx * A.csub + chunk) * NG * 256;
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(i * 4 + r) * 64 + lane] = G[i][r];
+}
+
+// LDS of a workgroup: stage-1 fragments, scale patch, row offsets (nq4 = the instance's cell slots rounded up to
+// four, ns = its ring slots)
+inline size_t split_lds_bytes(int nbq, int cs, int nq4, int ns) {
+  return ((size_t)nbq * cs * 64 + (size_t)nq4 * 16) * sizeof(double) + (size_t)ns * 64 * sizeof(uint32_t);
+}
+
+struct SplitReduceArgs {
+  const double *Gp;                    // [items][nchunk][NG][4][64]
+  int32_t items, nchunk, MC;           // MC row tiles in the kernel's order
+  int32_t m, mm;                       // logical rows, padded row count of d_G
+  int32_t normalise;
+  int16_t inv[7 * 16];                 // logical row -> the kernel's row (tile * 16 + column)
+  double *G;                           // [items][mm][mm]
+};
+
+// one workgroup per item: chunks summed in fixed order into an LDS image of the kernel-order Gram, then
+// written in logical order, optionally as G_ij / (sqrt(G_ii) sqrt(G_jj)) (0 where a row has norm 0)
+__global__ __launch_bounds__(256) void split_reduce_kernel(SplitReduceArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int item = blockIdx.x;
+  const int MM = A.MC * 16, LD = MM + 1;
+  const int NG = A.MC * (A.MC + 1) / 2;
+  const double *src = A.Gp + (size_t)item * A.nchunk * NG * 256;
+  for (int e = threadIdx.x; e < NG * 256; e += 256) {
+    double acc = 0.0;
+    for (int c = 0; c < A.nchunk; ++c) acc += src[(size_t)c * NG * 256 + e];
+    const int idx = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+    int m1 = 0, base = 0;
+    while (idx >= base + (A.MC - m1)) {
+      base += A.MC - m1;
+      ++m1;
+    }
+    const int m2 = m1 + (idx - base);
+    const int c1 = m1 * 16 + (lane >> 4) + 4 * r, c2 = m2 * 16 + (lane & 15);
+    smem[c1 * LD + c2] = acc;
+    if (m1 != m2) smem[c2 * LD + c1] = acc;
+  }
+  __syncthreads();
+  double *out = A.G + (size_t)item * A.mm * A.mm;
+  for (int e = threadIdx.x; e < A.mm * A.mm; e += 256) {
+    const int l1 = e / A.mm, l2 = e % A.mm;
+    double v = 0.0;
+    if (l1 < A.m && l2 < A.m) {
+      const int i1 = A.inv[l1], i2 = A.inv[l2];
+      v = smem[i1 * LD + i2];
+      if (A.normalise) {
+        const double d1 = sqrt(smem[i1 * LD + i1]), d2 = sqrt(smem[i2 * LD + i2]);
+        v = (d1 * d2 > 0.0) ? v / d1 / d2 : 0.0;
+      }
+    }
+    out[e] = v;
+  }
+}
+
+}  // namespace plsr

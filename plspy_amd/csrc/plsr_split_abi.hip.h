@@ -1,0 +1,202 @@
+// extern "C" entry points of K2s (two-stage split-half Gram, plsr_split.hip.h).  See include/plsr.h.
+#include "plsr_split.hip.h"
+
+namespace {
+struct SplitPlan {
+  int inst;                       // index into the instance table below
+  int NTB, NTO, NTT, CS, MC, NQ;  // the instance's (maximum) counts
+  bool exact;
+  int cs, nx, csub, NG;
+  int64_t ntile;
+  size_t lds;
+  size_t o_roff, o_bfrag, o_wfrag, o_gp, bytes;
+};
+
+struct SplitInstance {
+  int NTB, NTO, NTT, CS;
+  bool exact;
+};
+// exact instances first: config 4 (mb, two groups x three conditions, bscan of two: eight behaviour cells, twelve
+// task cells, twelve task rows) and the behaviour PLS of config 3's data (twelve behaviour cells)
+const SplitInstance kSplitInst[] = {{4, 6, 1, 3, true},  {6, 0, 0, 3, true},  {5, 5, 1, 3, false},
+                                    {6, 0, 0, 3, false}, {6, 0, 0, 5, false}, {2, 4, 1, 5, false}};
+
+bool split_plan(int32_t n, int64_t ldx, int64_t p, int32_t b, const int32_t *cell_rows, int32_t nq, int32_t nbq,
+                int32_t ktask, int32_t m, int32_t items, SplitPlan &pl) {
+  if (n <= 0 || p < 16 || ldx < p || b <= 0 || b > SG_BP || !cell_rows || nq <= 0 || nq > SG_MAXQ || nbq < 0 ||
+      nbq > nq || ktask < 0 || ktask > 16 || m <= 0 || items <= 0)
+    return false;
+  if ((int64_t)n * ldx * 8 >= ((int64_t)1 << 32)) return false;      // 32-bit row offsets
+  if (ktask == 0 && nbq != nq) return false;                         // task-only cells without task rows
+  int cs = 1, rmin = 1 << 30;
+  for (int q = 0; q < nq; ++q) {
+    if (cell_rows[q] < 0) return false;
+    cs = std::max(cs, (cell_rows[q] + 3) / 4);
+    rmin = std::min(rmin, cell_rows[q]);
+  }
+  const int ntb = (nbq + SG_IP - 1) / SG_IP, np = (nq + SG_IP - 1) / SG_IP;
+  pl.inst = -1;
+  for (int i = 0; i < (int)(sizeof(kSplitInst) / sizeof(kSplitInst[0])); ++i) {
+    const SplitInstance &I = kSplitInst[i];
+    bool ok;
+    if (I.exact)
+      ok = nbq == I.NTB * SG_IP && nq == (I.NTB + I.NTO) * SG_IP && (ktask > 0) == (I.NTT > 0) && cs == I.CS &&
+           rmin > 4 * (I.CS - 1);
+    else
+      ok = ntb <= I.NTB && np <= I.NTB + I.NTO && (ktask == 0 || I.NTT > 0) && cs <= I.CS;
+    if (ok) {
+      pl.inst = i;
+      pl.NTB = I.NTB, pl.NTO = I.NTO, pl.NTT = I.NTT, pl.CS = I.CS, pl.exact = I.exact;
+      break;
+    }
+  }
+  if (pl.inst < 0) return false;
+  pl.cs = cs;
+  pl.MC = pl.NTB + pl.NTT;
+  pl.NQ = (pl.NTB + pl.NTO) * SG_IP;
+  pl.NG = pl.MC * (pl.MC + 1) / 2;
+  if (m > pl.MC * 16) return false;
+  pl.ntile = (p + 15) / 16;
+  pl.nx = (int)std::min<int64_t>(8, pl.ntile);
+  {
+    // voxel ranges per item: the eight XCDs' eighths of X, cut further only while the launch has fewer than
+    // about four rounds of the chip's 1024 one-wave slots -- and never below 64 tiles per wave (the row
+    // offsets, the fragments and the 30 KB partial Gram are per wave)
+    const int64_t per_x = (pl.ntile + pl.nx - 1) / pl.nx;
+    const int64_t want = (4096 + (int64_t)items * pl.nx - 1) / ((int64_t)items * pl.nx);
+    pl.csub = (int)std::max<int64_t>(1, std::min<int64_t>(want, per_x / 64));
+  }
+  pl.lds = split_lds_bytes(nbq, cs, (pl.NQ + 3) / 4 * 4, pl.NQ * pl.CS);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  pl.o_roff = take((size_t)items * nq * cs * 4 * sizeof(uint32_t));
+  pl.o_bfrag = take((size_t)items * std::max(nbq, 1) * cs * 64 * sizeof(double));
+  pl.o_wfrag = take((size_t)((pl.NQ + 3) / 4) * 64 * sizeof(double));
+  pl.o_gp = take((size_t)items * pl.nx * pl.csub * pl.NG * 256 * sizeof(double));
+  pl.bytes = off;
+  return true;
+}
+
+template <int NTB, int NTO, int NTT, int CS, bool EXACT>
+int launch_split(const SplitArgs &a, const SplitPlan &pl, hipStream_t st) {
+  auto kern = split_gram_kernel<NTB, NTO, NTT, CS, EXACT>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.items * pl.nx * pl.csub)), dim3(64), pl.lds, st, a);
+  return launch_ok();
+}
+}  // namespace
+
+extern "C" size_t plsr_split_gram_workspace_bytes(int32_t n, int64_t ldx, int64_t p, int32_t b,
+                                                  const int32_t *cell_rows, int32_t nq, int32_t nbq, int32_t ktask,
+                                                  int32_t m, int32_t items) {
+  SplitPlan pl;
+  return split_plan(n, ldx, p, b, cell_rows, nq, nbq, ktask, m, items, pl) ? pl.bytes : 0;
+}
+
+extern "C" int plsr_split_gram(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_xsrc,
+                               const int32_t *d_ysrc, int32_t nz, const double *d_Y, int32_t b,
+                               const int32_t *cell_rows, int32_t nq, int32_t nbq, const double *d_Wc, int32_t ktask,
+                               const int32_t *row_cell, const int32_t *row_sub, int32_t m, int32_t normalise,
+                               int32_t items, double *d_G, void *d_work, size_t work_bytes, void *stream) {
+  if (!d_X || !d_xsrc || !d_G || !d_work || !cell_rows || !row_cell || !row_sub) return PLSR_EINVAL;
+  if (nbq > 0 && (!d_ysrc || !d_Y)) return PLSR_EINVAL;
+  if (ktask > 0 && !d_Wc) return PLSR_EINVAL;
+  SplitPlan pl;
+  if (!split_plan(n, ldx, p, b, cell_rows, nq, nbq, ktask, m, items, pl)) return PLSR_EUNSUPPORTED;
+  if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
+  {
+    int tot = 0;
+    for (int q = 0; q < nq; ++q) tot += cell_rows[q];
+    if (tot != nz) return PLSR_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char *w = (char *)d_work;
+
+  SplitMetaArgs ma;
+  ma.xsrc = d_xsrc;
+  ma.ysrc = d_ysrc;
+  ma.Y = d_Y;
+  ma.b = b;
+  ma.items = items;
+  ma.nz = nz;
+  ma.nq = nq;
+  ma.nbq = nbq;
+  ma.cs = pl.cs;
+  ma.cell_lo[0] = 0;
+  for (int q = 0; q < nq; ++q) ma.cell_lo[q + 1] = ma.cell_lo[q] + cell_rows[q];
+  ma.ldx_bytes = ldx * 8;
+  ma.roff = (uint32_t *)(w + pl.o_roff);
+  ma.bfrag = (double *)(w + pl.o_bfrag);
+  {
+    const int64_t total = (int64_t)items * nq * pl.cs * 4 + (int64_t)items * nbq * pl.cs * 64;
+    hipLaunchKernelGGL(split_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ma);
+  }
+  double *wfrag = (double *)(w + pl.o_wfrag);
+  if (pl.NTT) {
+    if (ktask > 0) {
+      hipLaunchKernelGGL(split_wfrag_kernel, dim3((unsigned)((pl.NQ + 3) / 4)), dim3(64), 0, st, d_Wc, ktask, nq, wfrag);
+    } else if (hipMemsetAsync(wfrag, 0, (size_t)((pl.NQ + 3) / 4) * 64 * sizeof(double), st) != hipSuccess) {
+      return PLSR_ELAUNCH;
+    }
+  }
+
+  SplitArgs a;
+  a.X = d_X;
+  a.p = p;
+  a.items = items;
+  a.nq = nq;
+  a.nbq = nbq;
+  a.cs = pl.cs;
+  for (int q = 0; q < SG_MAXQ; ++q) {
+    a.nrow[q] = q < nq ? cell_rows[q] : 0;
+    a.rn[q] = a.nrow[q] > 0 ? 1.0 / (double)a.nrow[q] : 0.0;
+  }
+  a.roff = ma.roff;
+  a.bfrag = ma.bfrag;
+  a.wfrag = pl.NTT ? wfrag : nullptr;
+  a.nx = pl.nx;
+  a.csub = pl.csub;
+  a.ntile = pl.ntile;
+  a.Gp = (double *)(w + pl.o_gp);
+  int rc = PLSR_EUNSUPPORTED;
+  switch (pl.inst) {
+    case 0: rc = launch_split<4, 6, 1, 3, true>(a, pl, st); break;
+    case 1: rc = launch_split<6, 0, 0, 3, true>(a, pl, st); break;
+    case 2: rc = launch_split<5, 5, 1, 3, false>(a, pl, st); break;
+    case 3: rc = launch_split<6, 0, 0, 3, false>(a, pl, st); break;
+    case 4: rc = launch_split<6, 0, 0, 5, false>(a, pl, st); break;
+    case 5: rc = launch_split<2, 4, 1, 5, false>(a, pl, st); break;
+  }
+  if (rc) return rc;
+
+  SplitReduceArgs ra;
+  ra.Gp = a.Gp;
+  ra.items = items;
+  ra.nchunk = pl.nx * pl.csub;
+  ra.MC = pl.MC;
+  ra.m = m;
+  ra.mm = (m + 15) / 16 * 16;
+  ra.normalise = normalise;
+  for (int l = 0; l < m; ++l) {
+    int at;
+    if (row_cell[l] >= 0) {
+      if (row_cell[l] >= nbq || row_sub[l] < 0 || row_sub[l] >= b) return PLSR_EINVAL;
+      at = (row_cell[l] / SG_IP) * 16 + (row_cell[l] % SG_IP) * SG_BP + row_sub[l];
+    } else {
+      if (!pl.NTT || row_sub[l] < 0 || row_sub[l] >= ktask) return PLSR_EINVAL;
+      at = (pl.MC - 1) * 16 + row_sub[l];
+    }
+    ra.inv[l] = (int16_t)at;
+  }
+  ra.G = d_G;
+  const size_t lds = (size_t)(pl.MC * 16) * (pl.MC * 16 + 1) * sizeof(double);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)split_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess)
+    return PLSR_ELAUNCH;
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)items), dim3(256), lds, st, ra);
+  return launch_ok();
+}

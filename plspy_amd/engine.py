@@ -425,6 +425,45 @@ class ProjectionEngine:
                                                     _ptr(work), need, _stream()), "plsr_gram_fused")
         return G
 
+    def split_gram(self, cells, Y):
+        """K2s (plsr_split_gram): the per-item Grams of behaviour / multiblock split-half items from their
+        cell description (split_half_resampling._cells_rb / _cells_mb), or None when the kernel's instances do
+        not serve the shape (the caller then takes gram_phase's fused path).  Returns (S, mm, mm) on the
+        device; the multiblock row normalisation is applied when cells["normalise"]."""
+        xsrc = np.ascontiguousarray(cells["xsrc"], dtype=np.int32)
+        ysrc = np.ascontiguousarray(cells["ysrc"], dtype=np.int32)
+        S, nz = xsrc.shape
+        rows = [int(x) for x in cells["cell_rows"]]
+        nq, nbq = len(rows), int(cells["nbq"])
+        Wc = cells.get("Wc")
+        ktask = 0 if Wc is None else int(Wc.shape[0])
+        m = len(cells["row_cell"])
+        Yd = self.dev(np.ascontiguousarray(Y, dtype=np.float64))
+        b = int(Yd.shape[1])
+        c_rows = (ctypes.c_int32 * nq)(*rows)
+        r_cell = (ctypes.c_int32 * m)(*[int(x) for x in cells["row_cell"]])
+        r_sub = (ctypes.c_int32 * m)(*[int(x) for x in cells["row_sub"]])
+        ldx = self.X.stride(0)
+        if not self.lib.plsr_split_gram_workspace_bytes(self.n, ldx, self.p, b, c_rows, nq, nbq, ktask, m, 1):
+            return None
+        mm = (m + 15) // 16 * 16
+        G = torch.empty((S, mm, mm), dtype=torch.float64, device=self.device)
+        Wd = self.dev(np.ascontiguousarray(Wc, dtype=np.float64)) if ktask else None
+        per_item = self.lib.plsr_split_gram_workspace_bytes(self.n, ldx, self.p, b, c_rows, nq, nbq, ktask, m, 64) // 64
+        step = max(1, min(S, self.work_limit // max(per_item, 1)))
+        for lo in range(0, S, step):
+            hi = min(S, lo + step)
+            cnt = hi - lo
+            need = self.lib.plsr_split_gram_workspace_bytes(self.n, ldx, self.p, b, c_rows, nq, nbq, ktask, m, cnt)
+            work = self._buf("k2work", need)
+            d_x = self.dev(xsrc[lo:hi], torch.int32)
+            d_y = self.dev(ysrc[lo:hi], torch.int32)
+            _lib.check(self.lib.plsr_split_gram(
+                _ptr(self.X), ldx, self.p, self.n, _ptr(d_x), _ptr(d_y), nz, _ptr(Yd), b, c_rows, nq, nbq, _ptr(Wd),
+                ktask, r_cell, r_sub, m, int(bool(cells.get("normalise"))), cnt, _ptr(G[lo:hi]), _ptr(work), need,
+                _stream()), "plsr_split_gram")
+        return G
+
     def gather_zscore(self, src, cell_lo, cell_z):
         """(items, nout, p) tensor: rows of X gathered by src (items x nout) and
         z-scored (ddof 0, / sqrt(n_cell)) within the output-row cells flagged in

@@ -189,25 +189,113 @@ def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2, centre=True):
     return rows, dict(src=src, cell_lo=cell_lo, cell_z=cell_z), k
 
 
-def _decompose(engine, rows, gather, k, row_normalise, contrasts=None):
+def _cells_rb(cond_order, splits, g1, g2):
+    """Cell description of the behaviour-PLS items for the two-stage Gram kernel (engine.split_gram): per
+    half, the group x condition cells of the half's row vector (consecutive blocks, split_half_resampling.py
+    :172-173, :203-204 -- read with the HALF's cond_order, like the reference), every one with b behaviour
+    rows.  Row l of the stacked cross-block [R1; R2] is behaviour l % b of cell l // b."""
+    nc = np.asarray(cond_order).shape[1]
+    xs, ys, rows = [], [], []
+    for gs, xk, yk in ((g1, "x1", "y1"), (g2, "x2", "y2")):
+        bb = cf.cell_bounds(_get_cond_order((sum(gs) * nc,), tuple(gs), nc))
+        xs.append(np.stack([d[xk] for d in splits]))
+        ys.append(np.stack([d[yk] for d in splits]))
+        rows += [int(hi - lo) for lo, hi in zip(bb[:-1], bb[1:])]
+    return dict(xsrc=np.concatenate(xs, axis=1), ysrc=np.concatenate(ys, axis=1), cell_rows=rows, nbq=len(rows),
+                Wc=None, normalise=False)
+
+
+def _cells_mb(cond_order, mctype, bscan, splits, g1, g2, centre=True):
+    """Cell description of the multiblock items: behaviour cells first (per half, group and bscan condition:
+    consecutive blocks of the half's bscan row vector, :160-161, :245-251), then the task cells (per half,
+    group and condition: blocks of the half's row vector) with the task rows' coefficients Wc -- the
+    mean-centring operator (or the plain cell means of cmb) is constant inside a cell.  None when it is not."""
+    cond_order = np.asarray(cond_order)
+    ng, nc = cond_order.shape
+    nbs = len(bscan)
+    xs, ys, rows_b, rows_t, Ws = [], [], [], [], []
+    for gs, xk, bk in ((g1, "xb1", "b1"), (g2, "xb2", "b2")):
+        co = _get_cond_order((sum(gs) * nc,), tuple(gs), nc)
+        bb = cf.cell_bounds(co[:, bscan])
+        xs.append(np.stack([d[xk] for d in splits]))
+        ys.append(np.stack([d[bk] for d in splits]))
+        rows_b += [int(hi - lo) for lo, hi in zip(bb[:-1], bb[1:])]
+    nbq = len(rows_b)
+    for gs, xk in ((g1, "x1"), (g2, "x2")):
+        co = _get_cond_order((sum(gs) * nc,), tuple(gs), nc)
+        cb = cf.cell_bounds(co)
+        W = _task_operator(co, mctype, centre)                         # (ng nc) x n_h
+        Wcell = W[:, cb[:-1]]
+        if not np.array_equal(W, np.repeat(Wcell, np.diff(cb), axis=1)):
+            return None
+        xs.append(np.stack([d[xk] for d in splits]))
+        ys.append(np.zeros_like(xs[-1]))
+        rows_t += [int(hi - lo) for lo, hi in zip(cb[:-1], cb[1:])]
+        Ws.append(Wcell)
+    nq = nbq + len(rows_t)
+    kt = ng * nc
+    Wc = np.zeros((2 * kt, nq))
+    Wc[:kt, nbq:nbq + ng * nc] = Ws[0]
+    Wc[kt:, nbq + ng * nc:] = Ws[1]
+    return dict(xsrc=np.concatenate(xs, axis=1), ysrc=np.concatenate(ys, axis=1), cell_rows=rows_b + rows_t,
+                nbq=nbq, Wc=Wc, normalise=True, ng=ng, nc=nc, nbs=nbs)
+
+
+def _cell_row_map(cells, k, b):
+    """row_cell / row_sub of engine.split_gram for the stacked cross-block's 2k rows."""
+    row_cell, row_sub = [], []
+    if cells["Wc"] is None:
+        for l in range(2 * k):
+            row_cell.append(l // b)
+            row_sub.append(l % b)
+    else:
+        ng, nc, nbs = cells["ng"], cells["nc"], cells["nbs"]
+        per = nc + nbs * b
+        for h in range(2):
+            for g in range(ng):
+                for r in range(per):
+                    if r < nc:
+                        row_cell.append(-1)
+                        row_sub.append((h * ng + g) * nc + r)
+                    else:
+                        row_cell.append((h * ng + g) * nbs + (r - nc) // b)
+                        row_sub.append((r - nc) % b)
+    return row_cell, row_sub
+
+
+def _grams(engine, item, lo, hi):
+    """(hi - lo, mm, mm) Grams of the stacked cross-blocks of items lo..hi on the device, the multiblock row
+    normalisation (class_functions.py:503-505: G_ij / (|row_i| |row_j|)) applied."""
+    cells = item.get("cells")
+    if cells is not None:
+        sub = dict(cells, xsrc=cells["xsrc"][lo:hi], ysrc=cells["ysrc"][lo:hi])
+        G = engine.split_gram(sub, item["Y"])
+        if G is not None:
+            return G
+    rows, gather = item["dense"]()
+    sub = None if gather is None else dict(gather, src=gather["src"][lo:hi])
+    G = engine.gram_phase(rows[lo:hi], gather=sub)
+    if item["row_normalise"]:
+        Gh = G.cpu().numpy()
+        d = np.sqrt(np.einsum("sii->si", Gh))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            Gh = np.where((d[:, :, None] * d[:, None, :]) > 0, Gh / d[:, :, None] / d[:, None, :], 0.0)
+        G = torch.as_tensor(Gh, device=engine.device)
+    return G
+
+
+def _decompose(engine, item, contrasts=None):
     """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, G12) from the
     Jacobi eigen-decompositions of G11 / G22.  With contrasts C (k x q), where
     _run_pls_contrast (class_functions.py:126-162) gives U = C, s = row norms of
     C.T M, V = (C.T M).T:  (None, s1, None, None, C.T G12 C) with
     s1 = sqrt(diag(C.T G11 C))."""
     rank, nranks = dist.world()
-    S = rows.shape[0]
+    S, k = item["S"], item["k"]
     lo, hi = dist.shard_bounds(S, rank, nranks)
     mm = (2 * k + 15) // 16 * 16
     if hi > lo:
-        sub = None if gather is None else dict(gather, src=gather["src"][lo:hi])
-        G = engine.gram_phase(rows[lo:hi], gather=sub)
-        if row_normalise:
-            Gh = G.cpu().numpy()
-            d = np.sqrt(np.einsum("sii->si", Gh))
-            with np.errstate(divide="ignore", invalid="ignore"):
-                Gh = np.where((d[:, :, None] * d[:, None, :]) > 0, Gh / d[:, :, None] / d[:, None, :], 0.0)
-            G = torch.as_tensor(Gh, device=engine.device)
+        G = _grams(engine, item, lo, hi)
     else:
         G = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device)
     if contrasts is not None:
@@ -252,23 +340,35 @@ def _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine):
         import torch.distributed as td
         td.broadcast_object_list(drawn, src=0)
     splits, g1, g2 = drawn[0]
+    item = dict(S=len(splits), Y=Y, row_normalise=pls_alg in ("mb", "cmb"))
     if pls_alg in ("mct", "cst"):
         rows, gather, k = _items_mct(cond_order, mctype, n, splits, g1, g2, centre=pls_alg == "mct")
+        item.update(k=k, dense=lambda: (rows, gather))
     elif pls_alg in ("rb", "csb"):
-        rows, gather, k = _items_rb(cond_order, Y, splits, g1, g2)
+        b = np.asarray(Y).shape[1]
+        k = cond_order.size * b
+        cells = _cells_rb(cond_order, splits, g1, g2)
+        item.update(k=k, cells=cells, dense=lambda: _items_rb(cond_order, Y, splits, g1, g2)[:2])
     else:
-        rows, gather, k = _items_mb(cond_order, mctype, Y, list(bscan), splits, g1, g2, centre=pls_alg == "mb")
-    return engine, rows, gather, k
+        b = np.asarray(Y).shape[1]
+        k = cond_order.shape[0] * (cond_order.shape[1] + len(bscan) * b)
+        cells = _cells_mb(cond_order, mctype, list(bscan), splits, g1, g2, centre=pls_alg == "mb")
+        item.update(k=k, cells=cells,
+                    dense=lambda: _items_mb(cond_order, mctype, Y, list(bscan), splits, g1, g2, centre=pls_alg == "mb")[:2])
+    if item.get("cells") is not None:
+        item["cells"]["row_cell"], item["cells"]["row_sub"] = _cell_row_map(item["cells"], item["k"], b)
+    return engine, item
 
 
 def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts=None,
                           bscan=None, Xbscan=None, Ybscan=None, engine=None):
     """split_half_resampling.py:23-401."""
-    engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
+    engine, item = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
+    k = item["k"]
     d = k if contrasts is None else np.asarray(contrasts).shape[1]             # :79-86
     if matrix.shape[1] < d:
         raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
-    U1, s1, _, _, G12 = _decompose(engine, rows, gather, k, pls_alg in ("mb", "cmb"), contrasts)
+    U1, s1, _, _, G12 = _decompose(engine, item, contrasts)
     train = np.repeat(s1[:, None, :], d, axis=1)                       # :195 (row broadcast, Q11)
     if contrasts is None:
         test = _inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U1)    # :196
@@ -294,8 +394,8 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
 def split_half(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts=None, bscan=None,
                Xbscan=None, Ybscan=None, lv=1, CI=0.95, engine=None):
     """split_half_resampling.py:404-861."""
-    engine, rows, gather, k = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
-    U1, s1, U2, s2, G12 = _decompose(engine, rows, gather, k, pls_alg in ("mb", "cmb"), contrasts)
+    engine, item = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
+    U1, s1, U2, s2, G12 = _decompose(engine, item, contrasts)
     if contrasts is None:
         u_rep = (_inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U2)) * _inv(s2)[:, None, :]   # :682
         v_rep = np.transpose(U1, (0, 2, 1)) @ U2                                                         # :683
