@@ -129,9 +129,42 @@ struct SplitArgs {
 };
 
 
+// 1 / sqrt(x) for a normal, positive x without the library routine's range checks (they came out as divergent
+// branches in the middle of the MFMA stream): v_rsq_f64 seeds about 26 bits, the second-order correction
+// y0 + y0 e (1/2 + 3/8 e), e = 1 - x y0^2, leaves an error of e^3
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y0), y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
+constexpr int split_gram_m1(int MC, int idx) {
+  int m1 = 0, base = 0;
+  while (idx >= base + (MC - m1)) {
+    base += MC - m1;
+    ++m1;
+  }
+  return m1;
+}
+constexpr int split_gram_m2(int MC, int idx) {
+  int m1 = 0, base = 0;
+  while (idx >= base + (MC - m1)) {
+    base += MC - m1;
+    ++m1;
+  }
+  return m1 + (idx - base);
+}
+
 // NTB behaviour tiles (two cells each), NTO pairs of task-only cells, NTT (0 / 1) task tile, CS k-steps per
 // cell.  EXACT: the launch has exactly these counts and every cell has more than 4 (CS - 1) rows, so all
-// guards fold and only a cell's last k-step is masked.
+// guards fold and only a cell's last k-step is masked; the item's stage-1 fragments then live in registers
+// (the generic instances read them from LDS).
+//
+// The tile loop is software-pipelined by hand: iteration t forms the scaled rows D of tile t (statistics, stage
+// 1, scale) and, cell by cell between those steps, issues the Gram MFMAs of tile t - 1's rows -- sixty
+// independent MFMAs that fill the matrix pipe while the wave walks the dependent chain sum -> 4x4x4 MFMA ->
+// mean -> centred squares -> 4x4x4 MFMA -> rsqrt of the next tile (with one wave per SIMD nothing else would).
+// Scheduling barriers between the cells keep that interleave.
 template <int NTB, int NTO, int NTT, int CS, bool EXACT>
 __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   constexpr int IP = SG_IP;
@@ -141,6 +174,10 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   constexpr int MC = NTB + NTT;                    // row tiles of the Gram
   constexpr int NG = MC * (MC + 1) / 2;
   constexpr int NG4 = (NQ + 3) / 4;
+  constexpr int NGM = 4 * NG;                      // Gram MFMAs per tile
+  constexpr int GPC = (NGM + NQ - 1) / NQ;         // ... issued per cell of the next tile
+  constexpr bool BFREG = EXACT;
+  constexpr int NBF = NTB * IP * CS;
   static_assert(NQ <= SG_MAXQ && NS <= 63, "cell slots / outstanding loads");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -159,16 +196,11 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   const int64_t t_lo = min(x_hi, x_lo + (int64_t)sub * per_s), t_hi = min(x_hi, t_lo + per_s);
   const int chunk = xcd * A.csub + sub;
 
-  // ---- LDS: this item's stage-1 fragments, then the scale patch ----
-  double *bf = smem;                                // [nbq * cs][64]
-  double *st = smem + (size_t)nbq * cs * 64;        // [NQ][16]
-  {
-    const double *src = A.bfrag + (size_t)item * nbq * cs * 64;
-    for (int e = 0; e < nbq * cs; ++e) bf[e * 64 + lane] = src[e * 64 + lane];
-  }
-  // ---- per-slot row offsets (+ this lane's voxel): LDS, [slot][lane] -- sixty of them in registers beside
-  // the ring's sixty pairs and the Gram's 120 accumulators left the config-4 instance 80 bytes of scratch ----
-  uint32_t *rl = (uint32_t *)(st + (size_t)NG4 * 4 * 16);
+  // ---- LDS: per-slot row offsets (+ this lane's voxel), [slot][lane] -- sixty of them in registers beside
+  // the ring's sixty pairs and the Gram's 120 accumulators left the config-4 instance 80 bytes of scratch;
+  // then (generic instances) this item's stage-1 fragments ----
+  uint32_t *rl = (uint32_t *)smem;                  // [NS][64]
+  double *bf = smem + NS * 32;                      // [nbq * cs][64]
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -177,6 +209,16 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
       rl[(q * CS + s) * 64 + lane] =
           A.roff[((size_t)item * nq * cs + (live ? q * cs + s : 0)) * 4 + kk] + (uint32_t)col * 8u;
     }
+  double bfr[BFREG ? NBF : 1];
+  {
+    const double *src = A.bfrag + (size_t)item * nbq * cs * 64;
+    if (BFREG) {
+#pragma unroll
+      for (int e = 0; e < NBF; ++e) bfr[e] = src[e * 64 + lane];
+    } else {
+      for (int e = 0; e < nbq * cs; ++e) bf[e * 64 + lane] = src[e * 64 + lane];
+    }
+  }
   asm volatile("" ::: "memory");
   // per-lane constants of the finalising layout: lane (i = kk, voxel = col) owns cell 4 g4 + i
   double cntl[NG4], rnl[NG4];
@@ -199,10 +241,21 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
     hot[u] = (lane & 3) == u ? 1.0 : 0.0;
     khot[u] = kk == u ? 1.0 : 0.0;
   }
+  // B operands that carry a group's scales from the finalising layout (A[m = voxel][k = cell-in-group]) into
+  // the accumulator layout of its two behaviour tiles: B[k][n = column] = 1 where column n belongs to cell k
+  double selb[2];
+  selb[0] = kk == (col >> 3) ? 1.0 : 0.0;
+  selb[1] = kk == 2 + (col >> 3) ? 1.0 : 0.0;
 
   f64x4 G[NG];
 #pragma unroll
   for (int i = 0; i < NG; ++i) G[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // the previous tile's scaled rows (zero before the first) and the ones being formed.  (The loop body written
+  // twice with the two sets' roles swapped, to save the copy at the end of a tile, spilled 700 bytes per lane:
+  // the set being formed must sit in VGPRs for its scaling, the copy is what moves it to accumulator registers.)
+  f64x4 Da[MC], Db[MC];
+#pragma unroll
+  for (int m = 0; m < MC; ++m) Da[m] = Db[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
   // tile t covers voxels [16 t, 16 t + 16); the last one is read from p - 16 and masks what tile t - 1 had
   auto tile_v0 = [&](int64_t t) { return min(16 * t, A.p - 16); };
@@ -213,13 +266,13 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) xr[j] = *(const double *)(b0 + rl[j * 64 + lane]);
   }
-  asm volatile("" ::: "memory");
 
-  for (int64_t tile = t_lo; tile < t_hi; ++tile) {
-    const int64_t v0 = tile_v0(tile);
-    const bool vvalid = v0 + col >= 16 * tile;
+  // forms the scaled rows D of `tile` and adds the Gram of the previous tile's rows Dc
+  auto body = [&](int64_t tile, const f64x4 (&Dc)[MC], f64x4 (&D)[MC]) __attribute__((always_inline)) {
+    const int64_t tcl = min(tile, t_hi - 1);
+    const int64_t v0 = tile_v0(tcl);
+    const bool vvalid = v0 + col >= 16 * tcl;
     const char *bn = Xb + tile_v0(min(tile + 1, t_hi - 1)) * 8;     // next tile's rows (the last tile re-reads itself)
-    f64x4 D[MC];
 #pragma unroll
     for (int m = 0; m < MC; ++m) D[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
@@ -230,77 +283,92 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int q = 4 * g4 + u;
-        if (q < NQ && (EXACT || q < nq)) {
-          const int t = q / IP;
-          const int nr = A.nrow[q];
-          double x[CS], xm[CS];
-#pragma unroll
-          for (int s = 0; s < CS; ++s) {
-            x[s] = xr[q * CS + s];
-            xr[q * CS + s] = *(const double *)(bn + rl[(q * CS + s) * 64 + lane]);   // slot refilled right after its use
-          }
-          // the lane's own rows of the cell (4 s + kk < n_c), summed; then over the four kk lanes
-          double s1p = 0.0;
-#pragma unroll
-          for (int s = 0; s < CS; ++s) {
-            const bool ok = (EXACT && s < CS - 1) || 4 * s + kk < nr;
-            xm[s] = ok ? x[s] : 0.0;
-            s1p += xm[s];
-          }
-          const double tot = mfma4_f64(one, s1p, 0.0);
-          totc[u] = tot;
-          if (t < NTB && (EXACT || q < nbq)) {
-            const double mean = tot * A.rn[q];
-            double ssp = 0.0;
+        if (q < NQ) {
+          if (EXACT || q < nq) {
+            const int t = q / IP;
+            const int nr = A.nrow[q];
+            double x[CS], xm[CS];
+            // the lane's own rows of the cell (4 s + kk < n_c), summed; then over the four kk lanes
+            double s1p = 0.0;
 #pragma unroll
             for (int s = 0; s < CS; ++s) {
+              x[s] = xr[q * CS + s];
               const bool ok = (EXACT && s < CS - 1) || 4 * s + kk < nr;
-              const double d = ok ? x[s] - mean : 0.0;
-              ssp = fma(d, d, ssp);
+              xm[s] = ok ? x[s] : 0.0;
+              s1p += xm[s];
             }
-            ssq = mfma4_f64(hot[u], ssp, ssq);
+            const double tot = mfma4_f64(one, s1p, 0.0);
+            totc[u] = tot;
+            if (t < NTB && (EXACT || q < nbq)) {
+              const double mean = tot * A.rn[q];
+              double ssp = 0.0;
 #pragma unroll
-            for (int s = 0; s < CS; ++s)
-              if (EXACT || s < cs) D[t] = mfma_f64(x[s], bf[(q * cs + s) * 64 + lane], D[t]);
+              for (int s = 0; s < CS; ++s) {
+                const bool ok = (EXACT && s < CS - 1) || 4 * s + kk < nr;
+                const double d = ok ? x[s] - mean : 0.0;
+                ssp = fma(d, d, ssp);
+              }
+              ssq = mfma4_f64(hot[u], ssp, ssq);
+#pragma unroll
+              for (int s = 0; s < CS; ++s)
+                if (EXACT || s < cs)
+                  D[t] = mfma_f64(x[s], BFREG ? bfr[BFREG ? q * CS + s : 0] : bf[(q * cs + s) * 64 + lane], D[t]);
+            }
+            // the cell's slots are requested again for the next tile AFTER their last use: requested ahead
+            // of it the loads needed registers of their own, and the ring was copied back -- behind an
+            // s_waitcnt vmcnt(0) -- at the end of every tile
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < CS; ++s) xr[q * CS + s] = *(const double *)(bn + rl[(q * CS + s) * 64 + lane]);
           }
+          // ---- this cell's share of the previous tile's Gram ----
+#pragma unroll
+          for (int j = q * GPC; j < (q + 1) * GPC && j < NGM; ++j) {
+            const int r = j / NG, idx = j % NG;
+            G[idx] = mfma_f64(Dc[split_gram_m1(MC, idx)][r], Dc[split_gram_m2(MC, idx)][r], G[idx]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // ---- the group's four cells: lane (i = kk, voxel = col) finalises cell 4 g4 + i ----
       // (a weighted sum with 0 / 1 weights: nested selects on values that live in accumulator registers
       // became divergent branches)
       const double s1sel = fma(totc[0], khot[0], fma(totc[1], khot[1], fma(totc[2], khot[2], totc[3] * khot[3])));
+      if (NTT) D[MC - 1] = mfma_f64(vvalid ? s1sel : 0.0, wf[g4], D[MC - 1]);
       if (4 * g4 < NTB * IP) {
         const double mean = s1sel * rnl[g4];
         const double em = 2.220446049250313e-16 * fabs(mean);
         const bool dead = !(ssq > cntl[g4] * em * em) || !vvalid;
-        st[(4 * g4 + kk) * 16 + (col & 3) * 4 + (col >> 2)] = dead ? 0.0 : rsqrt(ssq);
-      }
-      if (NTT) D[MC - 1] = mfma_f64(vvalid ? s1sel : 0.0, wf[g4], D[MC - 1]);
-      asm volatile("" ::: "memory");
-      // ---- scale the group's behaviour tiles: accumulator lane (col, kk), register r = voxel kk + 4 r ----
+        const double y = rsqrt_pos(dead ? 1.0 : ssq);
+        const double scv = dead ? 0.0 : y;
+        // scale the group's behaviour tiles: the scales cross into the accumulator layout (lane (column, kk),
+        // register r = voxel kk + 4 r) through one MFMA per tile
 #pragma unroll
-      for (int tt = 0; tt < 4 / IP; ++tt) {
-        const int t = g4 * (4 / IP) + tt;
-        if (t < NTB && (EXACT || t * IP < nbq)) {
-          const double *sp = st + (t * IP + (col >> 3)) * 16 + kk * 4;
+        for (int tt = 0; tt < 4 / IP; ++tt) {
+          const int t = g4 * (4 / IP) + tt;
+          if (t < NTB && (EXACT || t * IP < nbq)) {
+            const f64x4 sc4 = mfma_f64(scv, selb[tt], (f64x4){0.0, 0.0, 0.0, 0.0});
 #pragma unroll
-          for (int r = 0; r < 4; ++r) D[t][r] *= sp[r];
+            for (int r = 0; r < 4; ++r) D[t][r] *= sc4[r];
+          }
         }
       }
-      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
 
-    // ---- Gram of the tile's rows ----
-    {
-      int idx = 0;
+  // The first tile's loads are drained before the loop: the compiler's wait-count pass merges the state at
+  // the loop header with the back edge's, and with the prologue's sixty loads still pending (in whatever order
+  // the scheduler issued them) it put s_waitcnt vmcnt(0) at the top of EVERY tile; drained, it waits for exactly
+  // the cell's three slots (vmcnt(59), (58), (57)) and the other fifty-seven stay in flight.
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+  // one iteration more than there are tiles: the last one only has tile t_hi - 1's Gram to do (the rows it
+  // forms from the re-read last tile are dropped)
+  if (t_lo < t_hi) {
+    for (int64_t tile = t_lo; tile <= t_hi; ++tile) {
+      body(tile, Da, Db);
 #pragma unroll
-      for (int m1 = 0; m1 < MC; ++m1)
-#pragma unroll
-        for (int m2 = m1; m2 < MC; ++m2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) G[idx] = mfma_f64(D[m1][r], D[m2][r], G[idx]);
-          ++idx;
-        }
+      for (int m = 0; m < MC; ++m) Da[m] = Db[m];
     }
   }
 
@@ -311,10 +379,9 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
     for (int r = 0; r < 4; ++r) out[(i * 4 + r) * 64 + lane] = G[i][r];
 }
 
-// LDS of a workgroup: stage-1 fragments, scale patch, row offsets (nq4 = the instance's cell slots rounded up to
-// four, ns = its ring slots)
-inline size_t split_lds_bytes(int nbq, int cs, int nq4, int ns) {
-  return ((size_t)nbq * cs * 64 + (size_t)nq4 * 16) * sizeof(double) + (size_t)ns * 64 * sizeof(uint32_t);
+// LDS of a workgroup: row offsets of the instance's ns ring slots, then (generic instances) the stage-1 fragments
+inline size_t split_lds_bytes(int nbq, int cs, int ns, bool exact) {
+  return (size_t)ns * 64 * sizeof(uint32_t) + (exact ? 0 : (size_t)nbq * cs * 64 * sizeof(double));
 }
 
 struct SplitReduceArgs {
