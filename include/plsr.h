@@ -405,6 +405,7 @@ int plsr_gram_fused(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
  *   normalise      : G_ij / (sqrt(G_ii) sqrt(G_jj)) -- the multiblock row normalisation
  *                    (class_functions.py:503-505) applied to the Gram; rows of norm 0 give 0
  *   d_G            : [items][mm][mm], mm = 16 ceil(m / 16), rows / columns past m are 0
+ *   d_rownorm      : [items][mm] or null: the norms over all voxels of the un-normalised rows
  * The workspace query returns 0 for shapes the kernel's instances do not serve (b > 8, cells of more than 12
  * / 20 rows, more than 10-16 cells, X of 4 GiB or more, p < 16): plsr_gram_fused serves those.
  */
@@ -414,7 +415,7 @@ int plsr_split_gram(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     const int32_t *d_ysrc, int32_t nz, const double *d_Y, int32_t b, const int32_t *cell_rows,
                     int32_t nq, int32_t nbq, const double *d_Wc, int32_t ktask, const int32_t *row_cell,
                     const int32_t *row_sub, int32_t m, int32_t normalise, int32_t items, double *d_G,
-                    void *d_work, size_t work_bytes, void *stream);
+                    double *d_rownorm, void *d_work, size_t work_bytes, void *stream);
 
 /*
  * ---- F4: the upstream feed, X built on the device ---------------------------------

@@ -391,6 +391,7 @@ struct SplitReduceArgs {
   int32_t normalise;
   int16_t inv[7 * 16];                 // logical row -> the kernel's row (tile * 16 + column)
   double *G;                           // [items][mm][mm]
+  double *rownorm;                     // [items][mm] or null: sqrt of the raw diagonal (the rows' norms over all voxels)
 };
 
 // one workgroup per item: chunks summed in fixed order into an LDS image of the kernel-order Gram, then
@@ -430,6 +431,9 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(SplitReduceArgs A) {
     }
     out[e] = v;
   }
+  if (A.rownorm != nullptr)
+    for (int l = threadIdx.x; l < A.mm; l += 256)
+      A.rownorm[(size_t)item * A.mm + l] = l < A.m ? sqrt(smem[A.inv[l] * LD + A.inv[l]]) : 0.0;
 }
 
 }  // namespace plsr

@@ -100,7 +100,8 @@ extern "C" int plsr_split_gram(const double *d_X, int64_t ldx, int64_t p, int32_
                                const int32_t *d_ysrc, int32_t nz, const double *d_Y, int32_t b,
                                const int32_t *cell_rows, int32_t nq, int32_t nbq, const double *d_Wc, int32_t ktask,
                                const int32_t *row_cell, const int32_t *row_sub, int32_t m, int32_t normalise,
-                               int32_t items, double *d_G, void *d_work, size_t work_bytes, void *stream) {
+                               int32_t items, double *d_G, double *d_rownorm, void *d_work, size_t work_bytes,
+                               void *stream) {
   if (!d_X || !d_xsrc || !d_G || !d_work || !cell_rows || !row_cell || !row_sub) return PLSR_EINVAL;
   if (nbq > 0 && (!d_ysrc || !d_Y)) return PLSR_EINVAL;
   if (ktask > 0 && !d_Wc) return PLSR_EINVAL;
@@ -192,6 +193,7 @@ extern "C" int plsr_split_gram(const double *d_X, int64_t ldx, int64_t p, int32_
     ra.inv[l] = (int16_t)at;
   }
   ra.G = d_G;
+  ra.rownorm = d_rownorm;
   const size_t lds = (size_t)(pl.MC * 16) * (pl.MC * 16 + 1) * sizeof(double);
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void *)split_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

@@ -428,8 +428,9 @@ class ProjectionEngine:
     def split_gram(self, cells, Y):
         """K2s (plsr_split_gram): the per-item Grams of behaviour / multiblock split-half items from their
         cell description (split_half_resampling._cells_rb / _cells_mb), or None when the kernel's instances do
-        not serve the shape (the caller then takes gram_phase's fused path).  Returns (S, mm, mm) on the
-        device; the multiblock row normalisation is applied when cells["normalise"]."""
+        not serve the shape (the caller then takes gram_phase's fused path).  Returns (G (S, mm, mm), rownorm
+        (S, mm) or None) on the device; when cells["normalise"] the multiblock row normalisation is applied to
+        G and rownorm holds the norms of the un-normalised rows."""
         xsrc = np.ascontiguousarray(cells["xsrc"], dtype=np.int32)
         ysrc = np.ascontiguousarray(cells["ysrc"], dtype=np.int32)
         S, nz = xsrc.shape
@@ -448,6 +449,8 @@ class ProjectionEngine:
             return None
         mm = (m + 15) // 16 * 16
         G = torch.empty((S, mm, mm), dtype=torch.float64, device=self.device)
+        norm = bool(cells.get("normalise"))
+        rown = torch.empty((S, mm), dtype=torch.float64, device=self.device) if norm else None
         Wd = self.dev(np.ascontiguousarray(Wc, dtype=np.float64)) if ktask else None
         per_item = self.lib.plsr_split_gram_workspace_bytes(self.n, ldx, self.p, b, c_rows, nq, nbq, ktask, m, 64) // 64
         step = max(1, min(S, self.work_limit // max(per_item, 1)))
@@ -460,9 +463,9 @@ class ProjectionEngine:
             d_y = self.dev(ysrc[lo:hi], torch.int32)
             _lib.check(self.lib.plsr_split_gram(
                 _ptr(self.X), ldx, self.p, self.n, _ptr(d_x), _ptr(d_y), nz, _ptr(Yd), b, c_rows, nq, nbq, _ptr(Wd),
-                ktask, r_cell, r_sub, m, int(bool(cells.get("normalise"))), cnt, _ptr(G[lo:hi]), _ptr(work), need,
-                _stream()), "plsr_split_gram")
-        return G
+                ktask, r_cell, r_sub, m, int(norm), cnt, _ptr(G[lo:hi]), _ptr(rown[lo:hi]) if norm else _ptr(None),
+                _ptr(work), need, _stream()), "plsr_split_gram")
+        return G, rown
 
     def gather_zscore(self, src, cell_lo, cell_z):
         """(items, nout, p) tensor: rows of X gathered by src (items x nout) and

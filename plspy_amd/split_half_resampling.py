@@ -263,41 +263,96 @@ def _cell_row_map(cells, k, b):
     return row_cell, row_sub
 
 
-def _grams(engine, item, lo, hi):
-    """(hi - lo, mm, mm) Grams of the stacked cross-blocks of items lo..hi on the device, the multiblock row
-    normalisation (class_functions.py:503-505: G_ij / (|row_i| |row_j|)) applied."""
+# A singular value whose square is below this fraction of the largest one is refined (see _decompose):
+# the eigen-decomposition of a Gram loses eps (s_1 / s_i)^2 of relative accuracy, 2e-11 at this ratio
+REFINE_RATIO = 1e-5
+
+
+def _grams(engine, item, sel):
+    """(len(sel), mm, mm) Grams of the stacked cross-blocks of items `sel` on the device, the multiblock row
+    normalisation (class_functions.py:503-505: G_ij / (|row_i| |row_j|)) applied; and the norms of the
+    un-normalised rows ((len(sel), 2k) NumPy, or None when nothing is normalised)."""
     cells = item.get("cells")
     if cells is not None:
-        sub = dict(cells, xsrc=cells["xsrc"][lo:hi], ysrc=cells["ysrc"][lo:hi])
-        G = engine.split_gram(sub, item["Y"])
-        if G is not None:
-            return G
-    rows, gather = item["dense"]()
-    sub = None if gather is None else dict(gather, src=gather["src"][lo:hi])
-    G = engine.gram_phase(rows[lo:hi], gather=sub)
-    if item["row_normalise"]:
-        Gh = G.cpu().numpy()
-        d = np.sqrt(np.einsum("sii->si", Gh))
-        with np.errstate(divide="ignore", invalid="ignore"):
-            Gh = np.where((d[:, :, None] * d[:, None, :]) > 0, Gh / d[:, :, None] / d[:, None, :], 0.0)
-        G = torch.as_tensor(Gh, device=engine.device)
-    return G
+        sub = dict(cells, xsrc=cells["xsrc"][sel], ysrc=cells["ysrc"][sel])
+        res = engine.split_gram(sub, item["Y"])
+        if res is not None:
+            G, rown = res
+            return G, (rown[:, :2 * item["k"]] if rown is not None else None)
+    rows, gather = item["dense"](sel)
+    G = engine.gram_phase(rows, gather=gather)
+    if not item["row_normalise"]:
+        return G, None
+    Gh = G.cpu().numpy()
+    d = np.sqrt(np.einsum("sii->si", Gh))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Gh = np.where((d[:, :, None] * d[:, None, :]) > 0, Gh / d[:, :, None] / d[:, None, :], 0.0)
+    return torch.as_tensor(Gh, device=engine.device), torch.as_tensor(d[:, :2 * item["k"]], device=engine.device)
+
+
+def _structural_nulls(item):
+    """(nn1, nn2): how many singular values of each half's cross-block vanish for ANY data -- k minus the rank
+    of the half's rows as combinations of rows of X (a rank-deficient mean-centring, more behaviours than a
+    cell has degrees of freedom).  From the first item's stacked operator; these latent variables come out
+    of LAPACK as noise in the reference and as exact zeros here."""
+    rows, gather = item["dense"](np.array([0]))
+    k = item["k"]
+    rows = np.asarray(rows[0], dtype=float)
+    if gather is not None:                       # columns that read the same row of X act together
+        src = np.asarray(gather["src"][0])
+        agg = np.zeros((rows.shape[0], int(src.max()) + 1))
+        np.add.at(agg.T, src, rows.T)
+        rows = agg
+    out = []
+    for blk in (rows[:k], rows[k:2 * k]):
+        out.append(k - min(int(np.linalg.matrix_rank(blk)), item["p"]))
+    return tuple(out)
+
+
+def _refine(engine, item, sel, v1, v2, rown, passes):
+    """Refinement passes for the items `sel` (global ids) whose first-pass bases are v1 / v2 (len(sel), k, k):
+    the stacked operator rows are expressed in those bases (the halves' cross-blocks then have nearly
+    orthogonal rows with norms close to the singular values), their Gram is formed again -- entry (i, j) now
+    carries an error of eps s_i s_j instead of eps s_1^2 -- and Jacobi continues in relative mode from the
+    accumulated basis (engine.thin_svd_device does the same for the observed decomposition).  Returns
+    (e1, v1, e2, v2, H) as NumPy with H = v1^T G12 v2 in the refined bases."""
+    k = item["k"]
+    rows, gather = item["dense"](sel)
+    rows = np.array(rows, dtype=float)
+    if rown is not None:                         # the multiblock row normalisation, on the operator rows
+        with np.errstate(divide="ignore"):
+            rows *= np.where(rown > 0, 1.0 / rown, 0.0)[:, :, None]
+    for _ in range(passes):
+        R = np.concatenate((np.transpose(v1, (0, 2, 1)) @ rows[:, :k], np.transpose(v2, (0, 2, 1)) @ rows[:, k:2 * k]),
+                           axis=1)
+        G2 = engine.gram_phase(R, gather=gather)
+        e1, w1 = engine.eigh(G2, 0, k, init=engine.dev(np.ascontiguousarray(v1)), relative=True)
+        e2, w2 = engine.eigh(G2, k, k, init=engine.dev(np.ascontiguousarray(v2)), relative=True)
+        e1, w1, e2, w2, H0 = engine.fetch_async([e1, w1, e2, w2, G2[:, :k, k:2 * k].contiguous()]).get()
+        J1, J2 = np.transpose(v1, (0, 2, 1)) @ w1, np.transpose(v2, (0, 2, 1)) @ w2
+        H = np.transpose(J1, (0, 2, 1)) @ H0 @ J2
+        v1, v2 = np.array(w1), np.array(w2)
+    return np.array(e1), v1, np.array(e2), v2, H
 
 
 def _decompose(engine, item, contrasts=None):
-    """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, G12) from the
-    Jacobi eigen-decompositions of G11 / G22.  With contrasts C (k x q), where
-    _run_pls_contrast (class_functions.py:126-162) gives U = C, s = row norms of
-    C.T M, V = (C.T M).T:  (None, s1, None, None, C.T G12 C) with
-    s1 = sqrt(diag(C.T G11 C))."""
+    """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, H) from the Jacobi eigen-decompositions of the
+    Gram blocks G11 / G22, with H = U1^T G12 U2.  Items with a graded spectrum (a structurally live singular
+    value below sqrt(REFINE_RATIO) of the largest) get refinement passes (_refine), so that every live
+    singular value keeps LAPACK's accuracy; latent variables that are null for any data (_structural_nulls)
+    are returned as exact zeros -- the reference thresholds nothing here (split_half_resampling.py:194-196),
+    its values for them are rounding noise.
+    With contrasts C (k x q), where _run_pls_contrast (class_functions.py:126-162) gives U = C, s = row
+    norms of C.T M, V = (C.T M).T:  (None, s1, None, None, C.T G12 C) with s1 = sqrt(diag(C.T G11 C))."""
     rank, nranks = dist.world()
     S, k = item["S"], item["k"]
     lo, hi = dist.shard_bounds(S, rank, nranks)
     mm = (2 * k + 15) // 16 * 16
+    eps = np.finfo(float).eps
     if hi > lo:
-        G = _grams(engine, item, lo, hi)
+        G, rown = _grams(engine, item, np.arange(lo, hi))
     else:
-        G = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device)
+        G, rown = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device), None
     if contrasts is not None:
         (Gall,), _ = dist.exchange([G[:, :2 * k, :2 * k].contiguous()], [], S)
         Gall = Gall.cpu().numpy()
@@ -307,18 +362,32 @@ def _decompose(engine, item, contrasts=None):
     if hi > lo:
         e1, v1 = engine.eigh(G, 0, k)
         e2, v2 = engine.eigh(G, k, k)
+        got = engine.fetch_async([e1, v1, e2, v2, G[:, :k, k:2 * k].contiguous()] + ([rown] if rown is not None else []))
+        nn1, nn2 = _structural_nulls(item)           # (host work beside the kernels)
+        e1, v1, e2, v2, G12, *rest = (np.array(a) for a in got.get())
+        H = np.transpose(v1, (0, 2, 1)) @ G12 @ v2
+        tol = np.full((hi - lo, 1), 64 * k * eps)
+        # graded spectra: the smallest structurally live eigenvalue against the largest
+        ratio = np.minimum(e1[:, max(k - nn1 - 1, 0)] / np.maximum(e1[:, 0], np.finfo(float).tiny),
+                           e2[:, max(k - nn2 - 1, 0)] / np.maximum(e2[:, 0], np.finfo(float).tiny))
+        need = np.flatnonzero(ratio < REFINE_RATIO)
+        if need.size:
+            deep = ratio[need] < 1e-9
+            for grp, passes in ((need[~deep], 1), (need[deep], 2)):
+                if grp.size:
+                    r = _refine(engine, item, lo + grp, v1[grp], v2[grp], rest[0][grp] if rest else None, passes)
+                    e1[grp], v1[grp], e2[grp], v2[grp], H[grp] = r
+            tol[need] = (4 * k * eps) ** 2
+        for e, nn in ((e1, nn1), (e2, nn2)):
+            e[e <= tol * np.maximum(e[:, :1], 0.0)] = 0.0
+            if nn:
+                e[:, k - nn:] = 0.0
     else:
-        e1 = e2 = torch.zeros((0, k), dtype=torch.float64, device=engine.device)
-        v1 = v2 = torch.zeros((0, k, k), dtype=torch.float64, device=engine.device)
-    G12 = G[:, :k, k:2 * k].contiguous()
-    (e1, v1, e2, v2, G12), _ = dist.exchange([e1, v1, e2, v2, G12], [], S)
-    e1, v1, e2, v2, G12 = (t.cpu().numpy() for t in (e1, v1, e2, v2, G12))
-    tol = 64 * k * np.finfo(float).eps
-
-    def sv(e):
-        live = e > tol * np.maximum(e[:, :1], 0.0)
-        return np.sqrt(np.where(live, e, 0.0))
-    return v1, sv(e1), v2, sv(e2), G12
+        e1, v1, e2, v2, H = (np.zeros(shape) for shape in ((0, k), (0, k, k), (0, k), (0, k, k), (0, k, k)))
+    if nranks > 1:
+        send, _ = dist.exchange([engine.dev(np.ascontiguousarray(a)) for a in (e1, v1, e2, v2, H)], [], S)
+        e1, v1, e2, v2, H = (t.cpu().numpy() for t in send)
+    return v1, np.sqrt(e1), v2, np.sqrt(e2), H
 
 
 def _inv(s):
@@ -340,21 +409,26 @@ def _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine):
         import torch.distributed as td
         td.broadcast_object_list(drawn, src=0)
     splits, g1, g2 = drawn[0]
-    item = dict(S=len(splits), Y=Y, row_normalise=pls_alg in ("mb", "cmb"))
+    item = dict(S=len(splits), Y=Y, p=p, row_normalise=pls_alg in ("mb", "cmb"))
+
+    def pick(sel):
+        return [splits[int(i)] for i in sel]
+    # dense(sel): the stacked dense operators (len(sel), 2k, n') + gather table of the items `sel`, built on demand
     if pls_alg in ("mct", "cst"):
-        rows, gather, k = _items_mct(cond_order, mctype, n, splits, g1, g2, centre=pls_alg == "mct")
-        item.update(k=k, dense=lambda: (rows, gather))
+        k = _task_operator(_get_cond_order((sum(g1) * cond_order.shape[1],), tuple(g1), cond_order.shape[1]), mctype,
+                           pls_alg == "mct").shape[0]
+        item.update(k=k, dense=lambda sel: _items_mct(cond_order, mctype, n, pick(sel), g1, g2, centre=pls_alg == "mct")[:2])
     elif pls_alg in ("rb", "csb"):
         b = np.asarray(Y).shape[1]
         k = cond_order.size * b
         cells = _cells_rb(cond_order, splits, g1, g2)
-        item.update(k=k, cells=cells, dense=lambda: _items_rb(cond_order, Y, splits, g1, g2)[:2])
+        item.update(k=k, cells=cells, dense=lambda sel: _items_rb(cond_order, Y, pick(sel), g1, g2)[:2])
     else:
         b = np.asarray(Y).shape[1]
         k = cond_order.shape[0] * (cond_order.shape[1] + len(bscan) * b)
         cells = _cells_mb(cond_order, mctype, list(bscan), splits, g1, g2, centre=pls_alg == "mb")
-        item.update(k=k, cells=cells,
-                    dense=lambda: _items_mb(cond_order, mctype, Y, list(bscan), splits, g1, g2, centre=pls_alg == "mb")[:2])
+        item.update(k=k, cells=cells, dense=lambda sel: _items_mb(cond_order, mctype, Y, list(bscan), pick(sel), g1, g2,
+                                                                  centre=pls_alg == "mb")[:2])
     if item.get("cells") is not None:
         item["cells"]["row_cell"], item["cells"]["row_sub"] = _cell_row_map(item["cells"], item["k"], b)
     return engine, item
@@ -368,12 +442,13 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
     d = k if contrasts is None else np.asarray(contrasts).shape[1]             # :79-86
     if matrix.shape[1] < d:
         raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
-    U1, s1, _, _, G12 = _decompose(engine, item, contrasts)
+    U1, s1, U2, _, H = _decompose(engine, item, contrasts)
     train = np.repeat(s1[:, None, :], d, axis=1)                       # :195 (row broadcast, Q11)
     if contrasts is None:
-        test = _inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U1)    # :196
+        # V1.T M2.T U1 = S1^-1 U1.T G12 U1 = S1^-1 H (U1.T U2).T with H = U1.T G12 U2          (:196)
+        test = _inv(s1)[:, :, None] * (H @ np.transpose(np.transpose(U1, (0, 2, 1)) @ U2, (0, 2, 1)))
     else:
-        test = G12                                                     # V.T @ M2.T @ U = C.T M1 M2.T C (:220)
+        test = H                                                       # V.T @ M2.T @ U = C.T M1 M2.T C (:220)
     S = num_split
 
     def slab(a):
@@ -395,14 +470,14 @@ def split_half(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts
                Xbscan=None, Ybscan=None, lv=1, CI=0.95, engine=None):
     """split_half_resampling.py:404-861."""
     engine, item = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
-    U1, s1, U2, s2, G12 = _decompose(engine, item, contrasts)
+    U1, s1, U2, s2, H = _decompose(engine, item, contrasts)
     if contrasts is None:
-        u_rep = (_inv(s1)[:, :, None] * (np.transpose(U1, (0, 2, 1)) @ G12 @ U2)) * _inv(s2)[:, None, :]   # :682
+        u_rep = (_inv(s1)[:, :, None] * H) * _inv(s2)[:, None, :]       # V1.T V2 = S1^-1 U1.T G12 U2 S2^-1  (:682)
         v_rep = np.transpose(U1, (0, 2, 1)) @ U2                                                         # :683
     else:
         C = np.asarray(contrasts, dtype=float)
-        u_rep = G12                                                    # V1.T @ V2 = C.T M1 M2.T C  (:682)
-        v_rep = np.broadcast_to(C.T @ C, (G12.shape[0],) + (C.shape[1],) * 2)   # U1.T @ U2 = C.T C (:683)
+        u_rep = H                                                      # V1.T @ V2 = C.T M1 M2.T C  (:682)
+        v_rep = np.broadcast_to(C.T @ C, (H.shape[0],) + (C.shape[1],) * 2)     # U1.T @ U2 = C.T C (:683)
     S = num_split
 
     def slab(a):

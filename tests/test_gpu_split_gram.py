@@ -56,8 +56,8 @@ def _run(alg, groups, nc, b, bscan, p, S, seed, mctype=0, shift=0.0):
     _, item = sh._prepare(alg, X, Y, co, S, mctype, bscan, eng)
     cells = item["cells"]
     assert cells is not None
-    G = eng.split_gram(cells, Y)
-    return X, Y, cells, item, G, eng
+    res = eng.split_gram(cells, Y)
+    return X, Y, cells, item, (res[0] if res is not None else None), eng
 
 
 @pytest.mark.parametrize("case", [
@@ -90,7 +90,7 @@ def test_split_gram_matches_fused_dense_path():
     X, Y, cells, item, G, eng = _run("mb", (10, 12), 3, 4, [0, 1], 1500, 6, seed=11)
     assert G is not None
     dense = dict(item, cells=None)
-    Gd = sh._grams(eng, dense, 0, item["S"]).cpu().numpy()
+    Gd = sh._grams(eng, dense, np.arange(item["S"]))[0].cpu().numpy()
     m = 2 * item["k"]
     assert_close(G.cpu().numpy()[:, :m, :m], Gd[:, :m, :m], 1e-10, 1e-12, "two-stage vs fused dense")
 
@@ -118,5 +118,5 @@ def test_split_gram_declines_what_it_cannot_serve():
     np.random.seed(1)
     _, item = sh._prepare("rb", X, Y, co, 2, None, None, eng)
     assert eng.split_gram(item["cells"], Y) is None
-    G = sh._grams(eng, item, 0, item["S"])                # ... and the caller falls back to the fused Gram
+    G, _ = sh._grams(eng, item, np.arange(item["S"]))     # ... and the caller falls back to the fused Gram
     assert G.shape[0] == item["S"]
