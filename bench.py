@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=120, help="oracle iterations per loop for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pls-call", action="store_true", help="skip the PLS()-level rates")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the single-GPU shard emulation (strong_ceiling)")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed steps, rank 0 recomputes each whole job alone and compares it with "
                          "what the ranks exchanged (test switch; outside the timed region)")
@@ -132,7 +133,8 @@ def cpu_baseline(X, co, obs, iters):
     return {
         "value": 2 * iters / dt, "unit": "resamples/s", "cores": ncpu, "kind": "port",
         "sample": f"{iters} perm + {iters} boot iterations of the same 60x200000 mct problem (NumPy oracle, "
-                  f"direct form), {dt:.1f} s; threads limited to the {ncpu} CPUs usable here "
+                  f"direct form -- the reference's own loop, which also gathers X per iteration, measured 4.7 "
+                  f"resamples/s on 8 cores at survey time, SURVEY.md section 6), {dt:.1f} s; threads limited to the {ncpu} CPUs usable here "
                   f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota {quota}, os.cpu_count {os.cpu_count()}); "
                   f"BLAS pools {blas}",
     }
@@ -320,6 +322,34 @@ def main():
     if world == 1:
         jobs["weak"], results["weak"] = jobs["strong"], results["strong"]
 
+    # Single-GPU bound on the strong-scaling curve (N = 1 only): rank 0's share of the fixed job at N = 2 / 4 / 8
+    # -- R/N permutations + R/N bootstraps, the same launches a rank of an N-GPU run makes -- timed WITHOUT the
+    # collectives.  N GPUs cannot finish the job faster than this, so value_at_N <= total / t_shard: what limits
+    # the ceiling is the part of a step that does not shrink with the shard (operator / reduction kernels,
+    # launch gaps).  The exchange (48 KB gathered + 2 p k doubles all-reduced per phase) comes on top.
+    ceiling = None
+    if world == 1 and rank == 0 and not args.no_ceiling:
+        ceiling = {}
+        base = jobs["strong"]
+        csteps = max(10, min(args.steps, 60))
+        for N in (2, 4, 8):
+            plo, phi = dist.shard_bounds(NPERM, 0, N)
+            blo, bhi = dist.shard_bounds(NBOOT, 0, N)
+            sj = dict(base, RP=phi - plo, RB=bhi - blo, d_perm=eng.dev(base["perm_inds"][plo:phi], torch.int32),
+                      d_boot=eng.dev(base["boot_inds"][blo:bhi], torch.int32), local_perm=phi - plo, local_boot=bhi - blo)
+            el, bms, pms, _ = time_job(sj, csteps, 3)
+            t_shard = el / csteps
+            t_full = results["strong"]["elapsed"] / args.steps
+            ceiling[str(N)] = {
+                "shard": f"{phi - plo} perm + {bhi - blo} boot (rank 0 of {N})", "ms_per_step": t_shard * 1e3,
+                "resamples_per_s_ceiling": (NPERM + NBOOT) / t_shard,
+                "efficiency_ceiling": t_full / (N * t_shard),
+                "boot_launch_ms": float(np.mean(bms)) if bms else None,
+                "perm_launch_ms": float(np.mean(pms)) if pms else None,
+                "fixed_ms_outside_the_projection_kernels": (t_shard * 1e3 - float(np.mean(bms)) - float(np.mean(pms)))
+                if bms and pms else None,
+            }
+
     if rank == 0:
         n, p = N_ROWS, P_VOX
         # algorithmic flops per resample, dense direct form:
@@ -357,12 +387,26 @@ def main():
         # beside it: the kernel gets the same numbers with fewer flops, so that
         # rate can exceed the hardware peak and is not a utilisation figure.
         achieved = x_boot * per_launch / (bm * 1e-3) / 1e12
-        traffic = perm_traffic = None
+        # the dominant kernel's instance, from the launch plan (not a string that goes stale when the kernel does)
+        lay = eng.layout(k, per_launch)
+        plan = eng.plan(k, per_launch, k2=int(Xm.shape[0]), boot=True)
+        nh = (int(Xm.shape[0]) + 3) // 4
+        kernel_name = (f"plsr::project_boot_reg_kernel<{lay.nk}, false, {nh if nh in (1, 2) else -1}>" if plan["register_resident"]
+                       else f"plsr::project_kernel<{lay.period}, 1, {min(nh, 4)}>")
+        # roofline.traffic is a PMC measurement and cannot be taken inside the timed run (counters need their own
+        # passes, gpurun keeps them apart from traces): it is read from the committed summary of
+        # tools/collect_profiles.sh -- and only if that summary is about THIS kernel instance and launch size
+        traffic = perm_traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and per_launch == NBOOT:
             tj = json.load(open(tpath))
-            traffic = tj.get("boot_project_bytes_per_launch")
-            perm_traffic = tj.get("perm_project_bytes_per_launch")
+            if kernel_name.split("::", 1)[1] in tj.get("kernel", ""):
+                traffic = tj.get("boot_project_bytes_per_launch")
+                perm_traffic = tj.get("perm_project_bytes_per_launch")
+                traffic_source = ("profiles/hbm_traffic.json: " + tj.get("note", "")[:120] +
+                                  f"; kernel {tj.get('kernel')}; FETCH_SIZE + WRITE_SIZE per launch of {NBOOT} resamples")
+            else:
+                traffic_source = f"none: profiles/hbm_traffic.json is about {tj.get('kernel')}, this run launched {kernel_name}"
         line = {
             "metric": "resamples/sec (perm+boot), mct PLS X=60x200000",
             "value": head["value"], "unit": "resamples/s", "n_gpus": world, "steps": args.steps,
@@ -376,13 +420,13 @@ def main():
                        "parallelism": f"resample-sharded x{world}"},
             "backend": (td.get_backend() if world > 1 else None),
             "world_size": (td.get_world_size() if world > 1 else 1),
-            "strong": sm["strong"], "weak": sm["weak"],
+            "strong": sm["strong"], "weak": sm["weak"], "strong_ceiling": ceiling,
             "end_to_end_resamples_per_s": head["end_to_end_resamples_per_s"],
             "host_index_generation_and_upload_s_per_step": head["host_index_generation_and_upload_s_per_step"],
             "roofline": {
-                "bound": "mfma", "kernel": "plsr::project_boot_reg_kernel<15, false, 2> (bootstrap projection, K1br)",
+                "bound": "mfma", "kernel": kernel_name + " (bootstrap projection)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": bm, "launches": len(r["boot_ms"]), "resamples_per_launch": per_launch,
                 "algorithmic_flop_per_resample": f_boot,
                 "executed_flop_per_resample": x_boot,

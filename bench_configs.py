@@ -10,6 +10,12 @@
   --config 7   mct X=(128x200000) groups [8]x8 x 2 (k = 16: LDS-fed bootstrap kernel, period 4)
   --config 8   mct X=(64x200000)  groups [16,16] x 2 (sixteen k-steps: register-resident kernels at nk = 16)
 
+``--gpus N`` (N > 1): one rank per GPU over RCCL, resamples / splits sharded by plspy_amd/dist.py exactly as
+BASELINE.json's configs 4 ("sharded 4xMI355X") and 5 ("sharded 8xMI355X") ask.  Without a launcher's RANK /
+WORLD_SIZE in the environment the script starts its own ranks through torch.distributed.run BEFORE anything
+touches the GPU (the parent never imports torch), relays rank 0's line and exits with the child's code; rank 0
+prints the line, which records ``backend`` and ``world_size``.
+
 ``--count`` sets the number of resamples per loop (BASELINE's full counts are
 2000/2000, 1000 splits, 5000/5000); rates are per second of the resampling
 phase, host index generation and operator construction included, from the second
@@ -18,6 +24,8 @@ JSON object per run."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,31 +49,71 @@ def timed(fn, label=None):
     first touch of several GiB: 0.2-0.7 s on some boxes of the pool, 0 on others), which is a
     property of the box, not of the path.  The cold time is reported beside it (COLD)."""
     import torch
+    import torch.distributed as td
+    multi = td.is_available() and td.is_initialized()
     for rep in range(2 if label else 1):
         torch.cuda.synchronize()
+        if multi:
+            td.barrier()
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
+        if multi:                      # a phase ends when its last rank does
+            td.barrier()
         dt = time.perf_counter() - t0
         if label and rep == 0:
             COLD[label] = dt
     return out, dt
 
 
+def self_launch(args):
+    """N fresh rank processes through torch.distributed.run (as bench.py does); this process has not imported
+    torch and never will."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, cwd=os.path.dirname(os.path.abspath(__file__)), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, required=True)
     ap.add_argument("--count", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1)
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
-    torch.cuda.set_device(0)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = None
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        import torch.distributed as td
+        # PLSR_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks then share devices)
+        backend = os.environ.get("PLSR_DIST_BACKEND", "nccl")
+        dev_id = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(dev_id)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_id}"))
+        else:
+            td.init_process_group(backend)
+    else:
+        torch.cuda.set_device(0)
     import plspy_amd
     from plspy_amd import split_half_resampling as sh
     from plspy_amd.bootstrap_permutation import ResampleTest
     from plspy_amd.engine import ProjectionEngine
 
     np.random.seed(1234)
-    out = {"config": args.config, "device": torch.cuda.get_device_name(0)}
+    out = {"config": args.config, "device": torch.cuda.get_device_name(0), "n_gpus": world, "world_size": world,
+           "backend": backend}
     if args.config in (2, 5, 7, 8):
         # 7 / 8: mct shapes that used to run spilling instances -- k = 16, n = 128 (LDS-fed bootstrap,
         # period 4) and n = 64 (the sixteen-step register-resident kernels)
@@ -129,7 +177,11 @@ def main():
                    seconds_observed=t_obs, seconds_perm=t_perm, seconds_boot=t_boot, perms_per_s=R / t_perm,
                    boots_per_s=R / t_boot)
     out["seconds_cold_first_run"] = COLD
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -447,6 +447,11 @@ int plsr_mask_apply_rows(const void *d_in, int32_t in_is_f32, int64_t ld_in, int
  */
 /* `count` draws of np.random.permutation(n) -> out[count][n] */
 int plsr_rng_permutation(uint32_t *key, int32_t *pos, int32_t n, int32_t count, int32_t *out);
+/* `count` rounds of np.random.permutation(sizes[0]), ..., np.random.permutation(sizes[nsizes - 1]) in that
+ * order -> out[count][sum(sizes)]: the per-group subject shuffles of a split (split_half_resampling.py:136) and
+ * the subject + row shuffles of a null split (:271, :282 / :316) */
+int plsr_rng_permutation_seq(uint32_t *key, int32_t *pos, const int32_t *sizes, int32_t nsizes, int32_t count,
+                             int32_t *out);
 /* `count` task-PLS permutations (resample.py:63-73) -> out[count][nsub*nc] */
 int plsr_rng_task_permutations(uint32_t *key, int32_t *pos, const int32_t *table, int32_t nsub,
                                int32_t nc, int32_t count, int32_t *out);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "plsr_latent_xt_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
     "plsr_latent_xt": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_rng_permutation": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "plsr_rng_permutation_seq": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "plsr_rng_task_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "plsr_rng_bootstraps": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "plsr_rng_mb_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -96,6 +96,24 @@ extern "C" int plsr_rng_permutation(uint32_t *key, int32_t *pos, int32_t n, int3
   return PLSR_OK;
 }
 
+extern "C" int plsr_rng_permutation_seq(uint32_t *key, int32_t *pos, const int32_t *sizes, int32_t nsizes,
+                                        int32_t count, int32_t *out) {
+  if (!key || !pos || !sizes || !out || nsizes <= 0 || count < 0 || *pos < 0 || *pos > N) return PLSR_EINVAL;
+  for (int s = 0; s < nsizes; ++s)
+    if (sizes[s] <= 0) return PLSR_EINVAL;
+  MT mt{key, *pos};
+  int32_t *x = out;
+  for (int c = 0; c < count; ++c)
+    for (int s = 0; s < nsizes; ++s) {
+      const int n = sizes[s];
+      for (int i = 0; i < n; ++i) x[i] = i;
+      mt.shuffle(x, n);
+      x += n;
+    }
+  *pos = mt.pos;
+  return PLSR_OK;
+}
+
 extern "C" int plsr_rng_task_permutations(uint32_t *key, int32_t *pos, const int32_t *table,
                                           int32_t nsub, int32_t nc, int32_t count, int32_t *out) {
   if (!key || !pos || !table || !out || nsub <= 0 || nc <= 0 || count < 0 || *pos < 0 || *pos > N)

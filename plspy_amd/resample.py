@@ -108,6 +108,25 @@ def permutations(n, count, native=None):
     return out
 
 
+def permutation_rounds(sizes, count, native=None):
+    """``count`` rounds of np.random.permutation(sizes[0]), ..., np.random.permutation(sizes[-1]) in that order:
+    a list of (count, size) int32 arrays, one per entry of sizes."""
+    sizes = [int(x) for x in sizes]
+    out = np.empty((count, sum(sizes)), dtype=np.int32)
+    if count:
+        if NATIVE if native is None else native:
+            lib, L = _lib()
+            arr = (ctypes.c_int32 * len(sizes))(*sizes)
+            with _GlobalStream() as gs:
+                L.check(lib.plsr_rng_permutation_seq(*gs.args(), arr, len(sizes), count,
+                                                     out.ctypes.data_as(ctypes.c_void_p)), "plsr_rng_permutation_seq")
+        else:
+            for i in range(count):
+                out[i] = np.concatenate([np.random.permutation(s) for s in sizes])
+    offs = np.concatenate(([0], np.cumsum(sizes)))
+    return [out[:, a:b] for a, b in zip(offs[:-1], offs[1:])]
+
+
 def task_permutations(cond_order, count, native=None):
     table = np.ascontiguousarray(np.concatenate(subject_tables(cond_order)), dtype=np.int32)
     out = np.empty((count, table.size), dtype=np.int32)

@@ -53,49 +53,66 @@ def _draw_splits(pls_alg, cond_order, num_split, n, bscan):
     :266-283, :316).  Each entry: dict(x1, x2 = rows of X per half; y1, y2 =
     rows of Y per half (rb: permuted in the null, :316-318); b1, b2 = bscan rows
     per half (mb); xb1, xb2 = rows of X for the bscan part (mb: through the
-    null's row permutation of X, :282-283, :358)).  Returns (splits, g1, g2)."""
+    null's row permutation of X, :282-283, :358)).  Returns (splits, g1, g2).
+    The shuffles come from the native generator in two calls (all real splits, then all null splits:
+    a Python loop around np.random.permutation cost 15 us per split); the tables are formed for all
+    splits at once."""
     tables = resample.subject_tables(cond_order)
     alltab = np.concatenate(tables)
     nc = alltab.shape[1]
     mb = pls_alg in ("mb", "cmb")
-    out = []
-    g1 = g2 = None
-    for _ in range(num_split):
-        p1, p2, q1, q2, g1, g2 = [], [], [], [], [], []
-        for tbl in tables:
-            ns = tbl.shape[0]
-            half = int(np.floor(ns / 2))
-            t = tbl[np.random.permutation(ns), :]                    # :136
-            p1.append(t[:half, :].flatten())
-            p2.append(t[half:, :].flatten())
-            g1.append(len(p1[-1]) // nc)
-            g2.append(len(p2[-1]) // nc)
-            if mb:
-                q1.append(t[:half][:, bscan].flatten())              # :160-161
-                q2.append(t[half:][:, bscan].flatten())
-        x1, x2 = np.concatenate(p1), np.concatenate(p2)
-        d = dict(x1=x1, x2=x2, y1=x1, y2=x2)
+    S = num_split
+    halves = [int(np.floor(t.shape[0] / 2)) for t in tables]
+    g1 = [h for h in halves]
+    g2 = [t.shape[0] - h for t, h in zip(tables, halves)]
+    perms = resample.permutation_rounds([t.shape[0] for t in tables], S)             # :136, group by group
+    p1, p2, q1, q2 = [], [], [], []
+    for tbl, pm, half in zip(tables, perms, halves):
+        t = tbl[pm]                                                                   # (S, ns, nc)
+        p1.append(t[:, :half].reshape(S, -1))
+        p2.append(t[:, half:].reshape(S, -1))
         if mb:
-            d.update(b1=np.concatenate(q1), b2=np.concatenate(q2))
-            d.update(xb1=d["b1"], xb2=d["b2"])
-        out.append(d)
-    half = sum(g1)                                                   # :270 (last split's sizes, quirk Q12)
-    for _ in range(num_split):
-        t = alltab[np.random.permutation(n // nc), :]                # :271
-        i1, i2 = t[:half, :].flatten(), t[half:, :].flatten()
-        d = dict(x1=i1, x2=i2, y1=i1, y2=i2)
+            q1.append(t[:, :half][:, :, bscan].reshape(S, -1))                        # :160-161
+            q2.append(t[:, half:][:, :, bscan].reshape(S, -1))
+    x1, x2 = np.concatenate(p1, axis=1), np.concatenate(p2, axis=1)
+    cols = dict(x1=x1, x2=x2, y1=x1, y2=x2)
+    if mb:
+        b1, b2 = np.concatenate(q1, axis=1), np.concatenate(q2, axis=1)
+        cols.update(b1=b1, b2=b2, xb1=b1, xb2=b2)
+    real = cols
+    half = sum(g1)                                                   # :270 (the real splits' sizes, quirk Q12)
+    subj, rowp = resample.permutation_rounds([n // nc, n], S)                         # :271, then :282 / :316
+    t = alltab[subj]                                                                  # (S, nsub, nc)
+    i1, i2 = t[:, :half].reshape(S, -1), t[:, half:].reshape(S, -1)
+    null = dict(x1=i1, x2=i2, y1=i1, y2=i2)
+    if mb:
+        null.update(b1=t[:, :half][:, :, bscan].reshape(S, -1), b2=t[:, half:][:, :, bscan].reshape(S, -1))
+    rows = np.arange(S)[:, None]
+    if pls_alg in ("mct", "cst", "mb", "cmb"):
+        null.update(x1=rowp[rows, i1], x2=rowp[rows, i2])
         if mb:
-            d.update(b1=t[:half][:, bscan].flatten(), b2=t[half:][:, bscan].flatten())
-        if pls_alg in ("mct", "cst", "mb", "cmb"):
-            perm = np.random.permutation(n)                          # :282
-            d.update(x1=perm[i1], x2=perm[i2])
-            if mb:
-                d.update(xb1=perm[d["b1"]], xb2=perm[d["b2"]])       # :358: permx rows, unpermuted Y rows
-        else:
-            permy = np.random.permutation(n)                         # :316
-            d.update(y1=permy[i1], y2=permy[i2])
-        out.append(d)
+            null.update(xb1=rowp[rows, null["b1"]], xb2=rowp[rows, null["b2"]])      # :358: permx rows, unpermuted Y rows
+    else:
+        null.update(y1=rowp[rows, i1], y2=rowp[rows, i2])
+    out = _SplitTable({key: np.concatenate((real[key], null[key])) for key in real})
     return out, g1, g2
+
+
+class _SplitTable:
+    """The drawn splits as one (2 S, rows) int array per key; indexing gives a split's dict, slicing or an
+    index array a sub-table (the per-split dicts of round 2 cost a Python loop per use)."""
+
+    def __init__(self, cols):
+        self.cols = cols
+
+    def __len__(self):
+        return len(next(iter(self.cols.values())))
+
+    def take(self, sel):
+        return _SplitTable({k: v[sel] for k, v in self.cols.items()})
+
+    def stack(self, key):
+        return self.cols[key]
 
 
 def _task_operator(co, mctype, centre):
@@ -114,8 +131,8 @@ def _items_mct(cond_order, mctype, n, splits, g1, g2, centre=True):
     rows = np.zeros((S, 2 * k, n))
     ridx = np.arange(S)[:, None]
     # half-1 row r of the gathered block is X[x1[r]]: column x1[r] of the operator gets W1[:, r]
-    rows[ridx, :k, np.stack([d["x1"] for d in splits])] = W1.T[None]
-    rows[ridx, k:, np.stack([d["x2"] for d in splits])] = W2.T[None]
+    rows[ridx, :k, splits.stack("x1")] = W1.T[None]
+    rows[ridx, k:, splits.stack("x2")] = W2.T[None]
     return rows, None, k
 
 
@@ -134,12 +151,12 @@ def _items_rb(cond_order, Y, splits, g1, g2):
     S = len(splits)
     nbeh = Y.shape[1]
     rows = np.zeros((S, 2 * k, n))
-    src = np.concatenate((np.stack([d["x1"] for d in splits]), np.stack([d["x2"] for d in splits])),
+    src = np.concatenate((splits.stack("x1"), splits.stack("x2")),
                          axis=1).astype(np.int32)
     # all splits at once: z-score the halves' behaviour rows within cells and lay
     # them out as block-diagonal operator rows
     for h, (key, bb, coff, roff) in enumerate((("y1", b1, 0, 0), ("y2", b2, n1, k))):
-        Yz = cf.zscore_cells(Y[np.stack([d[key] for d in splits])], bb)          # S x n_h x b
+        Yz = cf.zscore_cells(Y[splits.stack(key)], bb)          # S x n_h x b
         for c, (lo, hi) in enumerate(zip(bb[:-1], bb[1:])):
             rows[:, roff + c * nbeh:roff + (c + 1) * nbeh, coff + lo:coff + hi] = np.transpose(Yz[:, lo:hi], (0, 2, 1))
     cell_lo = np.concatenate((b1, n1 + b2[1:]))
@@ -171,11 +188,11 @@ def _items_mb(cond_order, mctype, Y, bscan, splits, g1, g2, centre=True):
     width = n + nb1 + nb2
     S = len(splits)
     rows = np.zeros((S, 2 * k, width))
-    src = np.concatenate([np.stack([d[key] for d in splits]) for key in ("x1", "x2", "xb1", "xb2")],
+    src = np.concatenate([splits.stack(key) for key in ("x1", "x2", "xb1", "xb2")],
                          axis=1).astype(np.int32)
     for h, (xoff, boff, key) in enumerate(((0, n, "b1"), (n1, n + nb1, "b2"))):
         hv = halves[h]
-        Yz = cf.zscore_cells(Y[np.stack([d[key] for d in splits])], hv["bb"])     # S x nb_h x b, all splits at once
+        Yz = cf.zscore_cells(Y[splits.stack(key)], hv["bb"])     # S x nb_h x b, all splits at once
         for g in range(ng):
             r0 = h * k + g * per
             rows[:, r0:r0 + nc, xoff:xoff + hv["n"]] = hv["W"][g * nc:(g + 1) * nc]
@@ -198,8 +215,8 @@ def _cells_rb(cond_order, splits, g1, g2):
     xs, ys, rows = [], [], []
     for gs, xk, yk in ((g1, "x1", "y1"), (g2, "x2", "y2")):
         bb = cf.cell_bounds(_get_cond_order((sum(gs) * nc,), tuple(gs), nc))
-        xs.append(np.stack([d[xk] for d in splits]))
-        ys.append(np.stack([d[yk] for d in splits]))
+        xs.append(splits.stack(xk))
+        ys.append(splits.stack(yk))
         rows += [int(hi - lo) for lo, hi in zip(bb[:-1], bb[1:])]
     return dict(xsrc=np.concatenate(xs, axis=1), ysrc=np.concatenate(ys, axis=1), cell_rows=rows, nbq=len(rows),
                 Wc=None, normalise=False)
@@ -217,8 +234,8 @@ def _cells_mb(cond_order, mctype, bscan, splits, g1, g2, centre=True):
     for gs, xk, bk in ((g1, "xb1", "b1"), (g2, "xb2", "b2")):
         co = _get_cond_order((sum(gs) * nc,), tuple(gs), nc)
         bb = cf.cell_bounds(co[:, bscan])
-        xs.append(np.stack([d[xk] for d in splits]))
-        ys.append(np.stack([d[bk] for d in splits]))
+        xs.append(splits.stack(xk))
+        ys.append(splits.stack(bk))
         rows_b += [int(hi - lo) for lo, hi in zip(bb[:-1], bb[1:])]
     nbq = len(rows_b)
     for gs, xk in ((g1, "x1"), (g2, "x2")):
@@ -228,7 +245,7 @@ def _cells_mb(cond_order, mctype, bscan, splits, g1, g2, centre=True):
         Wcell = W[:, cb[:-1]]
         if not np.array_equal(W, np.repeat(Wcell, np.diff(cb), axis=1)):
             return None
-        xs.append(np.stack([d[xk] for d in splits]))
+        xs.append(splits.stack(xk))
         ys.append(np.zeros_like(xs[-1]))
         rows_t += [int(hi - lo) for lo, hi in zip(cb[:-1], cb[1:])]
         Ws.append(Wcell)
@@ -309,7 +326,7 @@ def _structural_nulls(item):
     return tuple(out)
 
 
-def _refine(engine, item, sel, v1, v2, rown, passes):
+def _refine(engine, item, sel, v1, v2, rown, passes, second=True):
     """Refinement passes for the items `sel` (global ids) whose first-pass bases are v1 / v2 (len(sel), k, k):
     the stacked operator rows are expressed in those bases (the halves' cross-blocks then have nearly
     orthogonal rows with norms close to the singular values), their Gram is formed again -- entry (i, j) now
@@ -327,17 +344,23 @@ def _refine(engine, item, sel, v1, v2, rown, passes):
                            axis=1)
         G2 = engine.gram_phase(R, gather=gather)
         e1, w1 = engine.eigh(G2, 0, k, init=engine.dev(np.ascontiguousarray(v1)), relative=True)
-        e2, w2 = engine.eigh(G2, k, k, init=engine.dev(np.ascontiguousarray(v2)), relative=True)
-        e1, w1, e2, w2, H0 = engine.fetch_async([e1, w1, e2, w2, G2[:, :k, k:2 * k].contiguous()]).get()
+        if second:
+            e2, w2 = engine.eigh(G2, k, k, init=engine.dev(np.ascontiguousarray(v2)), relative=True)
+            e1, w1, e2, w2, H0 = engine.fetch_async([e1, w1, e2, w2, G2[:, :k, k:2 * k].contiguous()]).get()
+        else:                                        # (the second half keeps its basis: nothing is asked of it)
+            e1, w1, H0 = engine.fetch_async([e1, w1, G2[:, :k, k:2 * k].contiguous()]).get()
+            e2, w2 = np.zeros_like(e1), v2
         J1, J2 = np.transpose(v1, (0, 2, 1)) @ w1, np.transpose(v2, (0, 2, 1)) @ w2
         H = np.transpose(J1, (0, 2, 1)) @ H0 @ J2
         v1, v2 = np.array(w1), np.array(w2)
     return np.array(e1), v1, np.array(e2), v2, H
 
 
-def _decompose(engine, item, contrasts=None):
+def _decompose(engine, item, contrasts=None, second=True):
     """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, H) from the Jacobi eigen-decompositions of the
-    Gram blocks G11 / G22, with H = U1^T G12 U2.  Items with a graded spectrum (a structurally live singular
+    Gram blocks G11 / G22, with H = U1^T G12 U2 (second=False: only the first half is decomposed, U2 = I and
+    s2 = 0 -- split_half_test_train asks nothing else of the second half).  Items with a graded spectrum (a
+    structurally live singular
     value below sqrt(REFINE_RATIO) of the largest) get refinement passes (_refine), so that every live
     singular value keeps LAPACK's accuracy; latent variables that are null for any data (_structural_nulls)
     are returned as exact zeros -- the reference thresholds nothing here (split_half_resampling.py:194-196),
@@ -361,21 +384,32 @@ def _decompose(engine, item, contrasts=None):
         return None, s1, None, None, C.T @ Gall[:, :k, k:] @ C
     if hi > lo:
         e1, v1 = engine.eigh(G, 0, k)
-        e2, v2 = engine.eigh(G, k, k)
-        got = engine.fetch_async([e1, v1, e2, v2, G[:, :k, k:2 * k].contiguous()] + ([rown] if rown is not None else []))
+        want = [e1, v1, G[:, :k, k:2 * k].contiguous()] + ([rown] if rown is not None else [])
+        if second:
+            want += list(engine.eigh(G, k, k))
+        got = engine.fetch_async(want)
         nn1, nn2 = _structural_nulls(item)           # (host work beside the kernels)
-        e1, v1, e2, v2, G12, *rest = (np.array(a) for a in got.get())
-        H = np.transpose(v1, (0, 2, 1)) @ G12 @ v2
+        got = [np.array(a) for a in got.get()]
+        e1, v1, G12 = got[:3]
+        rest = got[3:4] if rown is not None else []
+        if second:
+            e2, v2 = got[-2:]
+            H = np.transpose(v1, (0, 2, 1)) @ G12 @ v2
+        else:
+            e2, v2 = np.zeros_like(e1), np.broadcast_to(np.eye(k), v1.shape).copy()
+            H = np.transpose(v1, (0, 2, 1)) @ G12
         tol = np.full((hi - lo, 1), 64 * k * eps)
         # graded spectra: the smallest structurally live eigenvalue against the largest
-        ratio = np.minimum(e1[:, max(k - nn1 - 1, 0)] / np.maximum(e1[:, 0], np.finfo(float).tiny),
-                           e2[:, max(k - nn2 - 1, 0)] / np.maximum(e2[:, 0], np.finfo(float).tiny))
+        ratio = e1[:, max(k - nn1 - 1, 0)] / np.maximum(e1[:, 0], np.finfo(float).tiny)
+        if second:
+            ratio = np.minimum(ratio, e2[:, max(k - nn2 - 1, 0)] / np.maximum(e2[:, 0], np.finfo(float).tiny))
         need = np.flatnonzero(ratio < REFINE_RATIO)
         if need.size:
             deep = ratio[need] < 1e-9
             for grp, passes in ((need[~deep], 1), (need[deep], 2)):
                 if grp.size:
-                    r = _refine(engine, item, lo + grp, v1[grp], v2[grp], rest[0][grp] if rest else None, passes)
+                    r = _refine(engine, item, lo + grp, v1[grp], v2[grp], rest[0][grp] if rest else None, passes,
+                                second)
                     e1[grp], v1[grp], e2[grp], v2[grp], H[grp] = r
             tol[need] = (4 * k * eps) ** 2
         for e, nn in ((e1, nn1), (e2, nn2)):
@@ -412,7 +446,7 @@ def _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine):
     item = dict(S=len(splits), Y=Y, p=p, row_normalise=pls_alg in ("mb", "cmb"))
 
     def pick(sel):
-        return [splits[int(i)] for i in sel]
+        return splits.take(np.asarray(sel))
     # dense(sel): the stacked dense operators (len(sel), 2k, n') + gather table of the items `sel`, built on demand
     if pls_alg in ("mct", "cst"):
         k = _task_operator(_get_cond_order((sum(g1) * cond_order.shape[1],), tuple(g1), cond_order.shape[1]), mctype,
@@ -442,7 +476,7 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
     d = k if contrasts is None else np.asarray(contrasts).shape[1]             # :79-86
     if matrix.shape[1] < d:
         raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
-    U1, s1, U2, _, H = _decompose(engine, item, contrasts)
+    U1, s1, U2, _, H = _decompose(engine, item, contrasts, second=False)
     train = np.repeat(s1[:, None, :], d, axis=1)                       # :195 (row broadcast, Q11)
     if contrasts is None:
         # V1.T M2.T U1 = S1^-1 U1.T G12 U1 = S1^-1 H (U1.T U2).T with H = U1.T G12 U2          (:196)

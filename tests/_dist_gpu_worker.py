@@ -44,6 +44,31 @@ def run(single):
         Tvsc_orig=orc.group_condition_means(X @ orc.normalize(obs["V"]), co))
     out.update(mb_perm=rt.perm_debug_dict["s_list"], mb_std=rt.std_errs, mb_lvcorr=rt.LVcorr,
                mb_T=rt.boot_debug_dict["Tdistrib"])
+    out.update(run_split_half())
+    return out
+
+
+def run_split_half():
+    """The sharded split-half tests (split_half_resampling._decompose: shard_bounds over the 2 S items, one
+    packed all_gather of five tensors).  S = 3, 2 and 1: with two ranks the six items split evenly, with three
+    ranks four items split 2 / 1 / 1 (ragged) and two items leave the last rank without any."""
+    from plspy_amd import split_half_resampling as sh
+    co, X, Y = problems()
+    bscan = [0, 1]
+    from plspy_amd import class_functions as cf
+    mask = cf.bscan_mask(co, bscan)
+    out = {}
+    for alg, kw in (("mct", dict(mctype=0)), ("mb", dict(mctype=0, bscan=bscan, Xbscan=X[mask], Ybscan=Y[mask])),
+                    ("rb", dict())):
+        for S in (3, 2, 1):
+            np.random.seed(20 + S)
+            tt = sh.split_half_test_train(alg, X, Y if alg != "mct" else None, co, S, **kw)
+            res = sh.split_half(alg, X, Y if alg != "mct" else None, co, S, lv=2, CI=0.95, **kw)
+            for key in ("pls_s_train", "pls_s_test", "pls_s_train_null", "pls_s_test_null"):
+                out[f"sh_{alg}_{S}_tt_{key}"] = tt[key]
+            for key in ("pls_dist_u", "pls_dist_v", "pls_dist_null_u", "pls_dist_null_v"):
+                out[f"sh_{alg}_{S}_{key}"] = np.abs(res[key])       # (signs of singular vectors: Jacobi's)
+            out[f"sh_{alg}_{S}_rep_mean_u"] = np.array(res["pls_rep_mean_u"])
     return out
 
 

@@ -134,3 +134,80 @@ def test_guarded_batches_consume_the_stream_like_the_loop():
     np.random.seed(0)
     assert resample.draw_guarded(3, lambda m: (resample.permutations(4, m),),
                                  lambda rows: np.ones(len(rows), dtype=bool)) is None
+
+
+def test_permutation_rounds_match_numpy_and_stream_position():
+    """plsr_rng_permutation_seq: rounds of permutations of different lengths (the per-group subject
+    shuffles of a split, the subject + row shuffles of a null split) -- same values and same stream
+    position as the reference's loop (split_half_resampling.py:136, :271, :282)."""
+    from plspy_amd import resample
+    for seed, sizes in ((1, [20, 20]), (2, [6, 5, 7]), (3, [40, 120]), (4, [1, 3])):
+        np.random.seed(seed)
+        want = [np.empty((9, s), dtype=np.int32) for s in sizes]
+        for i in range(9):
+            for j, s in enumerate(sizes):
+                want[j][i] = np.random.permutation(s)
+        tail_a = np.random.randint(0, 1 << 30, size=3)
+        for native in (True, False):
+            np.random.seed(seed)
+            got = resample.permutation_rounds(sizes, 9, native=native)
+            tail_b = np.random.randint(0, 1 << 30, size=3)
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            np.testing.assert_array_equal(tail_a, tail_b)
+
+
+def test_split_draws_follow_the_reference_order():
+    """_draw_splits (vectorised, native shuffles) against the reference's per-split loop
+    (split_half_resampling.py:119-169, :266-283, :316) written out with np.random, for task,
+    behaviour and multiblock PLS and unequal groups."""
+    from plspy_amd import resample
+    from plspy_amd import split_half_resampling as sh
+    for alg, groups, nc, bscan in (("mct", (6, 5), 3, None), ("rb", (4, 4), 2, None), ("mb", (7, 6, 5), 3, [0, 2])):
+        co = np.array([[g] * nc for g in groups])
+        n, S = int(co.sum()), 5
+        tables = resample.subject_tables(co)
+        alltab = np.concatenate(tables)
+        np.random.seed(11)
+        want = []
+        for _ in range(S):
+            p1, p2, q1, q2 = [], [], [], []
+            for tbl in tables:
+                half = tbl.shape[0] // 2
+                t = tbl[np.random.permutation(tbl.shape[0])]
+                p1.append(t[:half].flatten())
+                p2.append(t[half:].flatten())
+                if bscan:
+                    q1.append(t[:half][:, bscan].flatten())
+                    q2.append(t[half:][:, bscan].flatten())
+            d = dict(x1=np.concatenate(p1), x2=np.concatenate(p2))
+            d.update(y1=d["x1"], y2=d["x2"])
+            if bscan:
+                d.update(b1=np.concatenate(q1), b2=np.concatenate(q2))
+                d.update(xb1=d["b1"], xb2=d["b2"])
+            want.append(d)
+        half = sum(t.shape[0] // 2 for t in tables)
+        for _ in range(S):
+            t = alltab[np.random.permutation(n // nc)]
+            i1, i2 = t[:half].flatten(), t[half:].flatten()
+            d = dict(x1=i1, x2=i2, y1=i1, y2=i2)
+            if bscan:
+                d.update(b1=t[:half][:, bscan].flatten(), b2=t[half:][:, bscan].flatten())
+            perm = np.random.permutation(n)
+            if alg == "rb":
+                d.update(y1=perm[i1], y2=perm[i2])
+            else:
+                d.update(x1=perm[i1], x2=perm[i2])
+                if bscan:
+                    d.update(xb1=perm[d["b1"]], xb2=perm[d["b2"]])
+            want.append(d)
+        tail_a = np.random.randint(0, 1 << 30, size=3)
+        np.random.seed(11)
+        got, g1, g2 = sh._draw_splits(alg, co, S, n, bscan)
+        tail_b = np.random.randint(0, 1 << 30, size=3)
+        np.testing.assert_array_equal(tail_a, tail_b)
+        assert g1 == [g // 2 for g in groups] and g2 == [g - g // 2 for g in groups]
+        assert len(got) == 2 * S
+        for i, d in enumerate(want):
+            for key, val in d.items():
+                np.testing.assert_array_equal(got.stack(key)[i], val, err_msg=f"{alg} split {i} {key}")
