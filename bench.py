@@ -245,22 +245,21 @@ def main():
             # the two phases are independent: the HBM-bound slab reductions that end the
             # bootstrap phase run on the engine's tail stream and overlap the MFMA-bound
             # permutation kernel (the projection kernels themselves stay serialised)
+            # (the same order as ResampleTest's task path: the permutation's operators on a side stream,
+            # bootstrap kernel, permutation kernel; exchange + final statistics of the bootstrap on the tail stream)
+            prep = eng.perm_prepare(k, d_perm, Md)
             res = eng.boot_phase(k, inds=d_boot, M=Md, ref=ref, Xm=Xm, overlap_tail=True)
-            ssq = eng.perm_phase(k, inds=d_perm, M=Md)
-            if world > 1:
-                # the bootstrap's collectives (one all_gather of the per-resample rows, one
-                # all_reduce of the moment block) are enqueued behind its reduction tail, on the
-                # tail stream: the moment sums cross xGMI while the permutation kernel runs
-                with eng.tail_stream():
-                    (bs, T), (S12,) = dist.exchange([res["ssq"], res["T"]], [res["S12"]], RB)
-                eng.join()
-                for t in (bs, T, S12):
-                    t.record_stream(torch.cuda.current_stream())
-                (ssq_all,), _ = dist.exchange([ssq], [], RP)
-            else:
-                eng.join()
-                ssq_all, bs, T, S12 = ssq, res["ssq"], res["T"], res["S12"]
-            sd, ratio = eng.boot_finalize(S12[0], S12[1], RB, num=ref)
+            ssq = eng.perm_phase(k, inds=d_perm, M=Md, prepared=prep)
+            # the bootstrap's collectives (one all_gather of the per-resample rows, one all_reduce of the
+            # moment block) and its final statistics are enqueued behind its reduction tail, on the tail
+            # stream: the moment sums cross xGMI while the permutation kernel runs
+            with eng.tail_stream():
+                (bs, T), (S12,) = dist.exchange([res["ssq"], res["T"]], [res["S12"]], RB)
+                sd, ratio = eng.boot_finalize(S12[0], S12[1], RB, num=ref)
+            eng.join()
+            for t in (bs, T, S12, sd, ratio):
+                t.record_stream(torch.cuda.current_stream())
+            (ssq_all,), _ = dist.exchange([ssq], [], RP)
             return ssq_all, bs, T, sd, ratio
         return step
 

@@ -183,11 +183,13 @@ class _ResampleTestPLS(ResampleTest):
     # shared pieces
     # ------------------------------------------------------------------
     @staticmethod
-    def _run_perm_device(eng, k, niter, inds=None, M=None, cols=None, beh=None):
+    def _run_perm_device(eng, k, niter, inds=None, M=None, cols=None, beh=None, prepared=None):
         """Shard the phase's resamples, run the permutation kernel, gather (device tensor)."""
         rank, nranks = dist.world()
         lo, hi = dist.shard_bounds(niter, rank, nranks)
-        if beh is not None:
+        if prepared is not None:
+            ssq = eng.perm_phase(k, prepared=prepared)
+        elif beh is not None:
             make, count = beh[0], hi - lo          # beh[0](a, z): Yz of this rank's resamples a..z
             ssq = eng.perm_phase(k, beh=(lambda a, z: make(lo + a, lo + z), beh[1], beh[2], count))
         elif cols is not None:
@@ -237,9 +239,14 @@ class _ResampleTestPLS(ResampleTest):
         else:
             inds = self._draw_on_rank0(lambda: resample.task_permutations(self._cond_order, niter))
         pending = []
+        # the operator fragments are built now, on a side stream: the bootstrap phase that is enqueued between
+        # this and launch() then does not wait for them
+        rank, nranks = dist.world()
+        lo, hi = dist.shard_bounds(niter, rank, nranks)
+        prepared = eng.perm_prepare(k, inds[lo:hi], M)
 
         def launch():
-            pending.append(eng.fetch_async([self._run_perm_device(eng, k, niter, inds=inds, M=M)]))
+            pending.append(eng.fetch_async([self._run_perm_device(eng, k, niter, inds=inds, M=M, prepared=prepared)]))
 
         def finish():
             s_obs = s
@@ -429,10 +436,15 @@ class _ResampleTestPLS(ResampleTest):
         early = {}
 
         def tail():
-            eng.join()
+            # exchange and final statistics on the tail stream, behind the reductions: they proceed while
+            # the main stream runs whatever was enqueued after the bootstrap kernel (the permutation)
             per = [res["ssq"], res["T"]] + ([res["vs"]] if keep_right_sv else [])
-            per, (S12,) = dist.exchange(per, [res["S12"]], niter)
-            sd, ratio = eng.boot_finalize(S12[0], S12[1], niter, num=ref)  # :695, :701
+            with eng.tail_stream():
+                per, (S12,) = dist.exchange(per, [res["S12"]], niter)
+                sd, ratio = eng.boot_finalize(S12[0], S12[1], niter, num=ref)  # :695, :701
+            eng.join()
+            for t in [sd, ratio, S12] + list(per):
+                t.record_stream(torch.cuda.current_stream())
             pending.append(eng.fetch_async([sd, ratio] + list(per)))
             if obs is not None:
                 # the p-free part of the host summary needs the observed X @ V only: formed here,

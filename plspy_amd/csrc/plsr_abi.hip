@@ -199,9 +199,15 @@ int pick_split(const plsr_layout_t *lay, int64_t nvt, int nw) {
     // the 2048 resident waves (one wave per workgroup, grid.y = k * splits); measured
     // at config 2: 5 / 10 / 20 / 30 rounds -> 2.71 / 2.69 / 2.72 / 2.81 ms, and fewer
     // runs re-read X less often
+    // ... and runs of at least eight tiles: a run loads its 4 nk X fragments once, and with four-tile runs
+    // (125 resamples per launch, a rank's share of config 2 on eight GPUs) the launch took 0.53 ms where
+    // 0.32 would be its share of the full launch
+    // (where the grid still has eight rounds of waves with them; small p keeps runs of four)
     const int tpl = lay->Rp / 16;
     const int64_t want = (10 * 2048 + nvt * lay->k - 1) / (nvt * lay->k);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(want, std::max(1, tpl / 4)));
+    const int64_t m4 = std::max<int64_t>(1, std::min<int64_t>(want, std::max(1, tpl / 4)));
+    const int64_t m8 = std::max<int64_t>(1, std::min<int64_t>(want, std::max(1, tpl / 8)));
+    return (int)(nvt * lay->k * m8 >= 8 * 2048 ? m8 : m4);
   }
   const int groups = (lay->ntiles + nw * lay->period - 1) / (nw * lay->period);
   int best = 1;

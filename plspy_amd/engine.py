@@ -191,11 +191,45 @@ class ProjectionEngine:
                        "plsr_ops_from_indices")
 
     # -- permutation ---------------------------------------------------------
-    def perm_phase(self, k, inds=None, M=None, cols=None, beh=None):
+    def perm_prepare(self, k, inds, M):
+        """The operator fragments of a permutation phase, built NOW on a side stream: when a bootstrap phase is
+        enqueued between this call and perm_phase(prepared=...), the permutation's operator kernel runs beside
+        the bootstrap's instead of between the two projection kernels (20 us of a rank's 0.85 ms step at
+        config 2 on eight GPUs).  The side stream starts behind everything the current stream holds so far
+        (the inputs; an earlier permutation kernel reading the same fragment buffer).  Returns a handle, or
+        None when the phase needs more than one batch."""
+        R = int(inds.shape[0])
+        if R == 0 or self.batch_size(k, 0, R) < R:
+            return None
+        lay = self.layout(k, R)
+        work, frag, need = self._scratch(lay, 0, "perm")
+        d_inds, Md = self.dev(inds, torch.int32), self.dev(M)
+        cur = torch.cuda.current_stream()
+        side = _side_stream(self.device, "ops")
+        ev0 = torch.cuda.Event()
+        ev0.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(ev0)
+            self._build_ops(lay, frag, inds=d_inds, M=Md)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        for t in (d_inds, Md, frag):
+            t.record_stream(side)
+        return dict(k=k, R=R, lay=lay, work=work, frag=frag, need=need, ready=ready)
+
+    def perm_phase(self, k, inds=None, M=None, cols=None, beh=None, prepared=None):
         """s_hat^2 (R x k) for every resample.  Either ``inds`` (R x n int32
         row selections) with ``M`` (n x k), or dense ``cols`` (R x k x n), or
         ``beh`` = (Yz (R, n, b) per-cell z-scored behaviour, U (cells*b, k),
-        rowcell (n,)) for the behaviour-PLS operator Yz_cell @ U_cell."""
+        rowcell (n,)) for the behaviour-PLS operator Yz_cell @ U_cell; or ``prepared``, the handle
+        of perm_prepare (operators already built)."""
+        if prepared is not None:
+            out = torch.empty((prepared["R"], k), dtype=torch.float64, device=self.device)
+            torch.cuda.current_stream().wait_event(prepared["ready"])
+            _lib.check(self.lib.plsr_perm_batch(_ptr(self.X), self.X.stride(0), self.p, _ptr(prepared["frag"]),
+                                                ctypes.byref(prepared["lay"]), _ptr(out), _ptr(prepared["work"]),
+                                                prepared["need"], _stream()), "plsr_perm_batch")
+            return out
         if beh is not None and callable(beh[0]):
             R = int(beh[3])                      # (Yz_fn(lo, hi), U, rowcell, R): Yz made batch by batch
         else:
@@ -235,7 +269,17 @@ class ProjectionEngine:
         refd = self.dev(ref)
         Xmd = self.dev(Xm)
         k2 = 0 if Xmd is None else int(Xmd.shape[0])
-        S12 = torch.zeros((2, self.p, k), dtype=torch.float64, device=self.device)   # one block: one all_reduce
+        if overlap_tail and self._tail is None:
+            self._tail = _side_stream(self.device, "tail")
+        if overlap_tail and R:
+            # the moment block is first touched by the merges on the tail stream: zeroed there, the fill (19 MB,
+            # 11 us at config 2) runs beside the operator kernels instead of in front of the projection
+            self._tail.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._tail):
+                S12 = torch.zeros((2, self.p, k), dtype=torch.float64, device=self.device)
+            S12.record_stream(torch.cuda.current_stream())
+        else:
+            S12 = torch.zeros((2, self.p, k), dtype=torch.float64, device=self.device)   # one block: one all_reduce
         S1, S2 = S12[0], S12[1]
         ssq = torch.empty((R, k), dtype=torch.float64, device=self.device)
         T = torch.empty((R, k, k2), dtype=torch.float64, device=self.device) if k2 else None
@@ -243,8 +287,6 @@ class ProjectionEngine:
         if R:
             step = self.batch_size(k, k2, R)
             Md = self.dev(M)
-            if overlap_tail and self._tail is None:
-                self._tail = _side_stream(self.device, "tail")
             if not overlap_tail:
                 self.join()          # an earlier overlapped tail may still read the bootstrap scratch
             tail = ctypes.c_void_p(self._tail.cuda_stream) if overlap_tail else ctypes.c_void_p(0)
