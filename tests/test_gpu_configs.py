@@ -318,3 +318,52 @@ def test_config6_mb_bootstrap_full_size():
         Td = orc.group_condition_means(orc.calculate_smeanmat(X[ti[b]], co, 0) @ Vh, co)
         assert_close(rt.boot_debug_dict["Tdistrib"][b][:, live], Td[:, live], 1e-8, 1e-11, f"mb Tdistrib[{b}]")
     assert np.isfinite(rt.std_errs).all()
+
+
+# ---------------------------------------------------------------------------
+# voxels with a strong, stable effect: |boot ratio| = |V s| / std_errs of 30 and of 1000
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("groups", [(10, 10), (12, 12)])        # n = 60: K1br (X in registers); n = 72: LDS-fed kernel
+def test_std_errs_of_high_ratio_voxels(groups):
+    """The bootstrap kernels accumulate plain sums of VS and VS^2 and shift them by the observed VS at
+    the merge (sum (x - ref)^2 = sum x^2 - 2 ref sum x + R ref^2), which cancels (ref / sd)^2 of the 2^53.
+    Planted: two blocks of voxels whose group x condition effect is 30 and 1000 times the noise -- the
+    voxels a user looks at.  std_errs against np.std of the directly projected bootstraps
+    (bootstrap_permutation.py:695-703)."""
+    import torch
+    from plspy_amd import operators, resample
+    from plspy_amd.engine import ProjectionEngine
+    nc, p, R = 3, 20_000, 1000
+    co = np.array([[g] * nc for g in groups])
+    n = int(co.sum())
+    rs = np.random.RandomState(17)
+    X = rs.randn(n, p)
+    cell = np.repeat(np.arange(co.size), co.reshape(-1))
+    effect = rs.randn(co.size)[cell]
+    blocks = {30.0: np.arange(1000, 1200), 1000.0: np.arange(9000, 9200)}
+    for amp, cols in blocks.items():
+        X[:, cols] += 0.12 * amp * effect[:, None] * (0.5 + rs.rand(len(cols)))[None, :]
+    W = operators.mean_centre_operator(co, 0)
+    Wm = operators.cell_mean_operator(co)
+    U, s, Vt = np.linalg.svd(W @ X, full_matrices=False)
+    s[np.abs(s) < 1e-12] = 0
+    V = Vt.T
+    k = U.shape[1]
+    live = s > 1e-10 * s.max()
+    eng = ProjectionEngine(X)
+    assert eng.plan(k, R, k2=k, boot=True)["register_resident"] == (n <= 64)
+    M = W.T @ U
+    ref = V * s
+    np.random.seed(99)
+    binds = resample.bootstraps(co, R)
+    res = eng.boot_phase(k, inds=eng.dev(binds, torch.int32), M=eng.dev(M), ref=eng.dev(ref), Xm=eng.apply_operator(Wm))
+    sd, ratio = eng.boot_finalize(res["S1"], res["S2"], R, num=eng.dev(ref))
+    sd, ratio = sd.cpu().numpy(), ratio.cpu().numpy()
+    a = _operators(M, binds)
+    for amp, cols in blocks.items():
+        VS = np.einsum("iv,bij->bvj", X[:, cols], a)
+        want = np.std(VS, axis=0)
+        r = np.abs(ref[cols] / want)[:, live]
+        assert amp < r.max() < 3 * amp, (amp, r.max())              # the block really holds ratios of that size
+        assert_close(sd[cols][:, live], want[:, live], 1e-9, 0, f"std_errs, |ratio| up to {r.max():.0f}")
+        assert_close(ratio[cols][:, live], (ref[cols] / want)[:, live], 1e-9, 0, f"boot_ratios, |ratio| up to {r.max():.0f}")
