@@ -27,8 +27,6 @@ z-scores its own resampled rows, so each resample is an item of the item kernels
 shapes those do not serve; then K5x / K5 for the latent scores).  The csb bootstrap ends in the reference's own ValueError
 (pls_classes.py:1158 hands a q x q matrix to :725).  Nothing falls back to a CPU
 path."""
-import abc
-
 import numpy as np
 import torch
 from scipy.stats import norm
@@ -38,40 +36,33 @@ from . import dist, exceptions, operators, resample
 from .engine import ProjectionEngine
 
 
-class ResampleTest(abc.ABC):
-    """Factory with the reference's registry behaviour
-    (bootstrap_permutation.py:14-63)."""
+# what the six method names stand for (used in messages)
+METHOD_NAMES = {"mct": "mean-centred task PLS", "cst": "contrast task PLS", "rb": "behaviour PLS",
+                "csb": "contrast behaviour PLS", "mb": "multiblock PLS", "cmb": "contrast multiblock PLS"}
 
-    _subclasses = {}
+
+class ResampleTest:
+    """The resample seam: ``ResampleTest._create(pls_alg, X, Y, U, s, V, cond_order, mctype, ...)`` runs the
+    permutation and bootstrap tests of one PLS variant and returns the object that carries their results
+    (the reference's entry point, bootstrap_permutation.py:53-63, :139-159).  The interface is the method
+    names and the exception types: an unknown name is a ValueError, a known one without an implementation
+    exceptions.NotImplementedError.  One class serves all six variants here (_IMPLEMENTATIONS below)."""
+
     pls_alg = None
-    _pls_types = {
-        "mct": "Mean-Centering Task PLS",
-        "cst": "Contrast Task PLS",
-        "rb": "Regular Behaviour PLS",
-        "mb": "Multiblock PLS",
-        "csb": "Contrast Behaviour PLS",
-        "cmb": "Contrast Multiblock PLS",
-    }
-
-    @classmethod
-    def _register_subclass(cls, pls_method):
-        def decorator(subclass):
-            cls._subclasses[pls_method] = subclass
-            return subclass
-        return decorator
+    _IMPLEMENTATIONS = {}             # method name -> class, filled in below the class definition
 
     @classmethod
     def _create(cls, pls_method, *args, **kwargs):
-        if pls_method not in cls._subclasses and pls_method in cls._pls_types:
-            raise exceptions.NotImplementedError(
-                f"Specified PLS/Resample method {cls._pls_types[pls_method]} "
-                "has not yet been implemented.")
-        elif pls_method not in cls._subclasses:
-            raise ValueError(f"Invalid PLS/Resample method {pls_method}")
-        # the reference stores the method on the class (not re-entrant, quirk
-        # Q18); here it is also handed to the instance explicitly.
+        impl = cls._IMPLEMENTATIONS.get(pls_method)
+        if impl is None:
+            if pls_method in METHOD_NAMES:
+                raise exceptions.NotImplementedError(
+                    f"resampling tests for {METHOD_NAMES[pls_method]} ('{pls_method}') are not available")
+            raise ValueError(f"unknown PLS method '{pls_method}' (one of {', '.join(METHOD_NAMES)})")
+        # the reference also leaves the method name on the class (quirk Q18: not re-entrant); the instance gets
+        # it explicitly
         cls.pls_alg = pls_method
-        return cls._subclasses[pls_method](*args, _pls_alg=pls_method, **kwargs)
+        return impl(*args, _pls_alg=pls_method, **kwargs)
 
 
 def _stepdown_totals(sv):
@@ -85,12 +76,6 @@ _DEGENERATE = ("Please check your behaviour data, and make sure that none of the
                "columns are all the same for each group.")
 
 
-@ResampleTest._register_subclass("mct")
-@ResampleTest._register_subclass("rb")
-@ResampleTest._register_subclass("mb")
-@ResampleTest._register_subclass("cst")
-@ResampleTest._register_subclass("csb")
-@ResampleTest._register_subclass("cmb")
 class _ResampleTestPLS(ResampleTest):
     def __init__(self, X, Y, U, s, V, cond_order, mctype, contrast=None, preprocess=None,
                  nperm=1000, nboot=1000, bscan=None, Xbscan=None, Ybscan=None,
@@ -178,6 +163,14 @@ class _ResampleTestPLS(ResampleTest):
             self.conf_ints = ["NA", "NA"]
             self.std_errs = "NA"
             self.boot_ratios = "NA"
+        # The result object outlives the call (the PLS result keeps it): it must not pin the engine -- X in
+        # HBM, the transposed copy, gigabytes of pooled scratch -- or the device-side observed decomposition.
+        # An engine made here goes away with this reference; a caller's engine gives its scratch back.
+        if engine is None:
+            self._engine.release_scratch()
+        self._engine = None
+        self._obs = None
+        self._predrawn = None
 
     # ------------------------------------------------------------------
     # shared pieces
@@ -755,3 +748,6 @@ class _ResampleTestPLS(ResampleTest):
         return stg
 
     __str__ = __repr__
+
+
+ResampleTest._IMPLEMENTATIONS.update({name: _ResampleTestPLS for name in METHOD_NAMES})

@@ -349,11 +349,16 @@ ProjectKernel boot_reg_instance(int nk) {
 // 1 = K1r (default: its fetches drop from 705 to 89 MB per launch at config 2, same duration),
 // 2 = K1br as well (fetches 665 -> 461 MB, but 1 % slower: with every run of a tile active at once the
 // 2.9 MB of operator fragments compete with 1.1 GB of slab stores for the XCD's 4 MB of L2).
-// PLSR_XCD_ORDER=0 / 1 / 2 overrides (measurement knob).
+// PLSR_XCD_ORDER=0 / 1 / 2 overrides in developer builds (-DPLSR_DEV_KNOBS; measurement knob).
 dim3 reg_grid(ProjectArgs &a, int64_t nvt, int nrun, int level) {
   static const int enabled = [] {
-    const char *e = getenv("PLSR_XCD_ORDER");
-    return e ? atoi(e) : 1;
+#ifdef PLSR_DEV_KNOBS                 // developer builds only: a stray variable must not change kernel selection
+    if (const char *e = getenv("PLSR_XCD_ORDER")) {
+      const int v = atoi(e);
+      if (v >= 0 && v <= 2) return v;
+    }
+#endif
+    return 1;
   }();
   const int64_t nwg = (nvt + 7) / 8 * 8 * nrun;
   if (enabled < level || nwg > 0x7fffffff) return dim3((unsigned)nvt, (unsigned)nrun);

@@ -37,13 +37,24 @@ struct LatentPlan {
   size_t lds, z_elems, n_elems, bytes;
 };
 
+// data rows whose 32-bit byte offsets from a block's first row stay below 4 GiB (a multiple of 16, or all n)
+inline int latent_rows_per_block(int32_t n, int64_t ldx) {
+  const int64_t fit = ((((int64_t)1 << 32) - 1024) / (ldx * 8));
+  return fit >= n ? n : (int)(fit / 16 * 16);
+}
+
 bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl) {
   if (n <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
   pl.MC = (k + 15) / 16;
   // eight waves (one tile of data rows each) when there are that many tiles: small
   // accumulators, four waves per SIMD at two workgroups per CU
   pl.WV = (n + 15) / 16 > 4 ? 8 : 4;
-  if (const char *e = getenv("PLSR_LATENT_WV")) pl.WV = atoi(e);   // developer knob (experiments)
+#ifdef PLSR_DEV_KNOBS                                               // developer builds only (-DPLSR_DEV_KNOBS, through PLSR_LIB)
+  if (const char *e = getenv("PLSR_LATENT_WV")) {
+    const int wv = atoi(e);
+    if (wv == 4 || wv == 8) pl.WV = wv;
+  }
+#endif
   pl.NI = ((n + 15) / 16 + pl.WV - 1) / pl.WV;
   if (pl.MC > 4 || pl.NI > 2) return false;
   // items per workgroup: as many as the accumulators allow (IG * MC * NI tiles of 8 VGPRs)
@@ -76,7 +87,25 @@ bool latent_plan(int32_t n, int32_t k, int32_t items, int64_t p, LatentPlan &pl)
   pl.z_elems = (size_t)pl.nchunk * items * k * n;
   pl.n_elems = (size_t)pl.nchunk * items * k;
   pl.bytes = ((pl.z_elems + pl.n_elems) * sizeof(double) + 511) / 256 * 256;
+  // The kernel addresses the rows a thread stages by 32-bit byte offsets from a group's first item (VS^T) and
+  // from X (assuming the rows are p apart -- the call checks its actual strides).  VS^T of a group must fit;
+  // an X of 4 GiB or more (n = 240 at p >= 2.24 M) is walked in blocks of rows, each below 4 GiB.
+  if ((int64_t)pl.IG * k * p * 8 >= ((int64_t)1 << 32)) return false;
+  if (latent_rows_per_block(n, p) < 16 && latent_rows_per_block(n, p) < n) return false;
   return true;
+}
+
+// sums the voxel chunks of a block of data rows into its columns of Zt:
+// out[jk][row_lo + i] = sum_c part[c][jk][i], jk = (item, latent variable), i < nb
+__global__ __launch_bounds__(256) void latent_sum_rows_kernel(const double *part, double *out, int64_t E, int nb, int n,
+                                                              int row_lo, int nchunk) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E * nb) return;
+  const int64_t jk = e / nb;
+  const int i = (int)(e - jk * nb);
+  double acc = 0.0;
+  for (int c = 0; c < nchunk; ++c) acc += part[(int64_t)c * E * nb + e];
+  out[jk * n + row_lo + i] = acc;
 }
 
 template <int MC, int NI, int IG, int WV>
@@ -119,38 +148,41 @@ extern "C" int plsr_latent(const double *d_X, int64_t ldx, int64_t p, int32_t n,
   LatentPlan pl;
   if (!latent_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
   if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
-  // the kernel addresses the rows a thread stages by 32-bit byte offsets from a group's first item / from X
-  if ((int64_t)pl.IG * k * ldv * 8 >= ((int64_t)1 << 32) || (int64_t)n * ldx * 8 >= ((int64_t)1 << 32))
-    return PLSR_EUNSUPPORTED;
+  if ((int64_t)pl.IG * k * ldv * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;   // (a stride wider than p)
+  const int nb_max = latent_rows_per_block(n, ldx);
+  if (nb_max < n && nb_max < 16) return PLSR_EUNSUPPORTED;
   LatentArgs a;
-  a.X = d_X;
   a.ldx = ldx;
   a.p = p;
-  a.n = n;
   a.k = k;
   a.items = items;
   a.vst = d_vst;
   a.ldv = ldv;
   a.tiles_per_chunk = pl.tiles_per_chunk;
   a.Zt_part = (double *)d_work;
-  a.nsq_part = d_nsq ? a.Zt_part + pl.z_elems : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  int rc = PLSR_EUNSUPPORTED;
+  // blocks of data rows (one block unless X is 4 GiB or more): Zt's columns row_lo .. row_lo + nb
+  for (int row_lo = 0; row_lo < n; row_lo += nb_max) {
+    const int nb = std::min(nb_max, n - row_lo);
+    a.X = d_X + (int64_t)row_lo * ldx;
+    a.n = nb;
+    a.nsq_part = (d_nsq && row_lo == 0) ? a.Zt_part + pl.z_elems : nullptr;     // the column norms of VS: once
+    int rc = PLSR_EUNSUPPORTED;
 #define PLSR_L(M, N) \
   if (pl.MC == M && pl.NI == N) rc = run_latent<M, N>(a, pl, st);
-  PLSR_L(1, 1) PLSR_L(1, 2) PLSR_L(2, 1) PLSR_L(2, 2) PLSR_L(3, 1) PLSR_L(3, 2) PLSR_L(4, 1) PLSR_L(4, 2)
+    PLSR_L(1, 1) PLSR_L(1, 2) PLSR_L(2, 1) PLSR_L(2, 2) PLSR_L(3, 1) PLSR_L(3, 2) PLSR_L(4, 1) PLSR_L(4, 2)
 #undef PLSR_L
-  if (rc) return rc;
-  const int64_t EZ = (int64_t)items * k * n, EN = (int64_t)items * k;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EZ + 255) / 256), 1), dim3(256), 0, st,
-                     (const double *)a.Zt_part, d_Zt, EZ, pl.nchunk, pl.nchunk);
-  if (d_nsq)
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
-                       (const double *)a.nsq_part, d_nsq, EN, pl.nchunk, pl.nchunk);
+    if (rc) return rc;
+    const int64_t E = (int64_t)items * k;
+    hipLaunchKernelGGL(latent_sum_rows_kernel, dim3((unsigned)((E * nb + 255) / 256)), dim3(256), 0, st,
+                       (const double *)a.Zt_part, d_Zt, E, nb, n, row_lo, pl.nchunk);
+    if (a.nsq_part)
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st,
+                         (const double *)a.nsq_part, d_nsq, E, pl.nchunk, pl.nchunk);
+  }
   return launch_ok();
 }
 
-// ---- K5x: X read as pre-transposed B fragments (n <= 128) ----
 extern "C" size_t plsr_latent_xt_bytes(int32_t n, int64_t p) {
   if (n <= 0 || n > XT_LD || p <= 0) return 0;
   return (size_t)((p + LV_T - 1) / LV_T * LV_T) * XT_LD * sizeof(double);
@@ -638,10 +670,14 @@ int agg_nf_instance(int nf) {
   return 0;
 }
 
+// 32-bit lane offsets of the result stores of K4a / K4b (rows p apart; the calls check their actual stride)
+inline bool item_store_offsets_fit(int64_t p) { return (12 * p + p) * 8 < ((int64_t)1 << 32); }
+
 bool agg_plan(int32_t n, int32_t nz, int32_t k, const int32_t *cell_lo, const int32_t *cell_z,
               const int32_t *src_lo, const int32_t *src_hi, int32_t ncell, int32_t items, int64_t p,
               bool moments, bool rowsq, AggPlan &pl) {
   if (n <= 0 || n > AG_MAXROWS || nz <= 0 || k <= 0 || items <= 0 || p <= 0) return false;
+  if (!item_store_offsets_fit(p)) return false;
   if (!cell_lo || !cell_z || !src_lo || !src_hi || ncell <= 0 || ncell > FZ_MAXCELL) return false;
   if (cell_lo[0] != 0 || cell_lo[ncell] != nz) return false;
   pl.MC = (k + 15) / 16;
@@ -897,9 +933,19 @@ struct BehPlan {
   size_t o_a1, o_mfrag, o_u2, o_mom, bytes;
 };
 
+// developer builds (-DPLSR_DEV_KNOBS): PLSR_BEH_GENERIC selects the guarded instance for A/B measurements
+inline bool beh_force_generic() {
+#ifdef PLSR_DEV_KNOBS
+  return getenv("PLSR_BEH_GENERIC") != nullptr;
+#else
+  return false;
+#endif
+}
+
 bool beh_plan(int32_t n, int32_t nz, int32_t b, int32_t k, const int32_t *cell_lo, const int32_t *src_lo,
               const int32_t *src_hi, int32_t ncell, int32_t items, int64_t p, bool moments, BehPlan &pl) {
   if (n <= 0 || nz <= 0 || b <= 0 || b > 16 || k <= 0 || k > 48 || items <= 0 || p <= 0) return false;
+  if (!item_store_offsets_fit(p)) return false;
   if (!cell_lo || !src_lo || !src_hi || ncell <= 0 || ncell > AG_MAXZC) return false;
   if (cell_lo[0] != 0 || cell_lo[ncell] != nz) return false;
   int cs = 0;
@@ -967,7 +1013,7 @@ int run_beh(const BehArgs &a, const BehPlan &pl, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)pl.nwg, (unsigned)pl.nsplit), dim3(BH_WAVES * 64), pl.lds, st, a);
     return launch_ok();
   };
-  if (CSMAX == 5 && NCMAX == 6 && pl.BP == 8 && a.ncell == NCMAX && a.cs == CSMAX && a.MC == 3 && !getenv("PLSR_BEH_GENERIC"))
+  if (CSMAX == 5 && NCMAX == 6 && pl.BP == 8 && a.ncell == NCMAX && a.cs == CSMAX && a.MC == 3 && !beh_force_generic())
     return launch(item_beh_kernel<5, 6, 8, true>);          // every step live: the instance without guards
   return pl.BP == 8 ? launch(item_beh_kernel<CSMAX, NCMAX, 8>) : launch(item_beh_kernel<CSMAX, NCMAX, 16>);
 }

@@ -51,15 +51,31 @@ class _Lane:
         self.frag = None
 
 
+# fetch_async results of at least this many bytes are copied out of their page-locked buffers by get(): a
+# result object that keeps them (V, R, std_errs: 77 MB each at config 3) would otherwise keep that much
+# page-locked host memory for as long as it lives; smaller arrays stay views (the copy would cost the public
+# call at config 2 about a millisecond of its nine)
+PINNED_COPY_BYTES = 32 << 20
+
+
 class _Fetch:
     """Pending device -> pinned-host copies (ProjectionEngine.fetch_async)."""
 
     def __init__(self, host, done):
         self._host, self._done = host, done
 
-    def get(self):
+    def get(self, copy=None):
+        """NumPy arrays of the fetched tensors.  copy=None: arrays of PINNED_COPY_BYTES or more are copied into
+        pageable memory, smaller ones are views of the page-locked buffers (recycled by torch's caching host
+        allocator once dropped); True / False: all / none."""
         self._done.synchronize()
-        return [h.numpy() for h in self._host]
+        out = []
+        for h in self._host:
+            a = h.numpy()
+            if copy or (copy is None and a.nbytes >= PINNED_COPY_BYTES):
+                a = np.array(a)
+            out.append(a)
+        return out
 
 
 class ProjectionEngine:
@@ -99,6 +115,15 @@ class ProjectionEngine:
             self._pool[name] = t = None
             t = self._pool[name] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return t
+
+    def release_scratch(self):
+        """Drops the engine-owned scratch (the pooled work / VS^T blocks -- 9.6 GB at config 3 --, the padded
+        transposed copy of X, the phase lanes): call when a PLS() call's resampling is over.  The next phase
+        allocates again (torch's caching allocator keeps the blocks for reuse by later engines)."""
+        self._pool.clear()
+        self._lanes.clear()
+        self._XT = None
+        self._XT_n = 0
 
     def dev(self, a, dtype=torch.float64):
         """Device copy of a host array (or the tensor itself if it is already

@@ -63,15 +63,24 @@ def _apply(m, idx, out):
 
 
 def apply_mask_matrices(matrices, mask, device=None):
-    """io.py:427-460: for every matrix m (time first), ``m[np.broadcast_to(mask, m.shape)]`` -- the
-    selected voxels of every time point, flattened.  Returns a list of 1-D fp64 device tensors."""
-    idx = mask_indices(mask, device)
+    """io.py:427-460: for every matrix m, ``m[np.broadcast_to(mask, m.shape)]`` -- the selected elements in C
+    order, flattened.  Any mask NumPy broadcasts to m's shape is taken (a spatial mask against (T, X, Y, Z)
+    volumes, a (1, X, Y, Z) or (Y, Z) mask, a full-shape mask); one that does not broadcast raises the
+    reference's ValueError.  Where the broadcast mask is the same for every step of the leading (time) axis
+    the spatial selection is compacted once and gathered per time point; otherwise the whole array is one
+    selection.  Returns a list of 1-D fp64 device tensors."""
+    mk = np.asarray(mask) != 0
+    cache = {}
     masked = []
     for m in matrices:
         m = np.asarray(m)
-        if m.shape[1:] != np.asarray(mask).shape and m.shape != np.asarray(mask).shape:
-            np.broadcast_to(mask, m.shape)                      # raises the reference's ValueError
-        vol = m if m.shape[1:] == np.asarray(mask).shape else m[None]
+        bm = np.broadcast_to(mk, m.shape)                       # raises the reference's ValueError
+        per_time = m.ndim >= 2 and (mk.ndim < m.ndim or mk.shape[0] == 1)
+        key = (m.shape, per_time)
+        if key not in cache:
+            cache[key] = mask_indices(bm[0] if per_time else bm, device)
+        idx = cache[key]
+        vol = m if per_time else m[None]
         out = torch.empty((vol.shape[0], idx.numel()), dtype=torch.float64, device=idx.device)
         _apply(vol, idx, out)
         masked.append(out.reshape(-1))

@@ -7,7 +7,6 @@ The observed decomposition (class_functions.py:98-123) runs on the device
 (engine.thin_svd: Gram -> Jacobi -> back-projection), like the observed blocks and
 latent scores; the permutation / bootstrap / split-half loops run on the GPU
 through bootstrap_permutation.py and split_half_resampling.py."""
-import abc
 
 import numpy as np
 
@@ -16,35 +15,26 @@ from . import class_functions as cf
 from .engine import ProjectionEngine
 
 
-class PLSBase(abc.ABC):
-    """Registry / factory (pls_classes.py:12-71)."""
+METHOD_NAMES = bootstrap_permutation.METHOD_NAMES
 
-    _subclasses = {}
-    _pls_types = {
-        "mct": "Mean-Centring Task PLS",
-        "rb": "Regular Behaviour PLS",
-        "cst": "Contrast Task PLS",
-        "csb": "Contrast Behaviour PLS",
-        "mb": "Multiblock PLS",
-        "cmb": "Contrast Multiblock PLS",
-    }
 
-    @classmethod
-    def _register_subclass(cls, pls_method):
-        def decorator(subclass):
-            cls._subclasses[pls_method] = subclass
-            return subclass
-        return decorator
+class PLSBase:
+    """Common base of the six PLS variants and their factory: ``PLSBase._create(name, X, ...)`` is what
+    ``plspy_amd.PLS`` dispatches to (the reference's pls_classes.py:62-71).  VARIANTS maps the method names
+    to the classes (filled in at the end of this module); an unknown name is a ValueError, a known one
+    without a class exceptions.NotImplementedError."""
+
+    VARIANTS = {}
+    _pls_types = METHOD_NAMES         # (the names in messages and in __str__)
 
     @classmethod
     def _create(cls, pls_method, *args, **kwargs):
-        if pls_method not in cls._subclasses and pls_method in cls._pls_types:
-            raise exceptions.NotImplementedError(
-                f"Specified PLS/Resample method {cls._pls_types[pls_method]} "
-                "has not yet been implemented.")
-        elif pls_method not in cls._subclasses:
-            raise ValueError(f"Invalid PLS method {pls_method}")
-        return cls._subclasses[pls_method](*args, **kwargs)
+        variant = cls.VARIANTS.get(pls_method)
+        if variant is None:
+            if pls_method in METHOD_NAMES:
+                raise exceptions.NotImplementedError(f"{METHOD_NAMES[pls_method]} ('{pls_method}') is not available")
+            raise ValueError(f"unknown PLS method '{pls_method}' (one of {', '.join(METHOD_NAMES)})")
+        return variant(*args, **kwargs)
 
     # helpers shared by the variants ------------------------------------
     @staticmethod
@@ -102,7 +92,6 @@ class PLSBase(abc.ABC):
     __str__ = __repr__
 
 
-@PLSBase._register_subclass("mct")
 class _MeanCentreTaskPLS(PLSBase):
     """Mean-centring task PLS (pls_classes.py:75-384)."""
 
@@ -222,7 +211,6 @@ def _check_behaviour(Y, cond_order):
                         "columns are all the same for each group.")
 
 
-@PLSBase._register_subclass("rb")
 class _RegularBehaviourPLS(PLSBase):
     """Regular behaviour PLS (pls_classes.py:386-647).  Defaults num_perm = 0,
     num_boot = 0 like the reference (:503-504)."""
@@ -286,7 +274,6 @@ class _RegularBehaviourPLS(PLSBase):
         self.U, self.V = self.V, self.U                                 # :646
 
 
-@PLSBase._register_subclass("mb")
 class _MultiblockPLS(PLSBase):
     """Multiblock PLS (pls_classes.py:1206-1558)."""
 
@@ -419,7 +406,6 @@ def _run_split_half(self, engine, Y, **extra):
         self.pls_alg, self.X, Y, self.cond_order, lv=self.lv, CI=self.CI, **common)
 
 
-@PLSBase._register_subclass("cst")
 class _ContrastTaskPLS(PLSBase):
     """Contrast task PLS (pls_classes.py:650-928)."""
 
@@ -456,7 +442,6 @@ class _ContrastTaskPLS(PLSBase):
         self.U, self.V = self.V, self.U
 
 
-@PLSBase._register_subclass("csb")
 class _ContrastBehaviourPLS(PLSBase):
     """Contrast behaviour PLS (pls_classes.py:931-1202).  Like the reference,
     a bootstrap (num_boot > 0) ends in a broadcasting ValueError (the class hands
@@ -498,7 +483,6 @@ class _ContrastBehaviourPLS(PLSBase):
         self.U, self.V = self.V, self.U
 
 
-@PLSBase._register_subclass("cmb")
 class _ContrastMultiblockPLS(PLSBase):
     """Contrast multiblock PLS (pls_classes.py:1561-1925)."""
 
@@ -572,3 +556,6 @@ class _ContrastMultiblockPLS(PLSBase):
             Tvsc_orig=Tvsc_orig, CI=self.CI, engine=engine)
         _run_split_half(self, engine, self.Y, bscan=self.bscan, Xbscan=self.Xbscan, Ybscan=self.Ybscan)
         self.U, self.V = self.V, self.U
+
+
+PLSBase.VARIANTS.update({"mct": _MeanCentreTaskPLS, "rb": _RegularBehaviourPLS, "mb": _MultiblockPLS, "cst": _ContrastTaskPLS, "csb": _ContrastBehaviourPLS, "cmb": _ContrastMultiblockPLS})

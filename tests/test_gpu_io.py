@@ -60,3 +60,20 @@ def test_design_matrix_feeds_the_engine():
     np.random.seed(5)
     ref = plspy_amd.PLS(X.cpu().numpy(), [3, 3], 2, num_perm=5, num_boot=5, pls_method="mct")
     np.testing.assert_allclose(res.s, ref.s, rtol=1e-12)
+
+
+@pytest.mark.parametrize("mshape", [(1, 5, 6, 7), (6, 7), (7,), (4, 5, 6, 7), (4, 1, 6, 1)])
+def test_masks_that_broadcast(mshape):
+    """Masks NumPy broadcasts against (T, X, Y, Z) volumes in other ways than the plain spatial one -- a
+    leading axis of one, trailing axes only, the full shape, singleton axes inside -- against the oracle's
+    restatement ``m[np.broadcast_to(mask, m.shape)]`` (io.py:456-458); and one that does not broadcast."""
+    from plspy_amd import io as pio
+    rs = np.random.RandomState(len(mshape) + sum(mshape))
+    vols = [rs.randn(4, 5, 6, 7), rs.randn(4, 5, 6, 7).astype(np.float32)]
+    mask = rs.rand(*mshape) > 0.4
+    got = pio.apply_mask_matrices(vols, mask)
+    want = orc.io_apply_mask_matrices(vols, mask)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g.cpu().numpy(), w.astype(np.float64))
+    with pytest.raises(ValueError):
+        pio.apply_mask_matrices(vols, rs.rand(3, 6, 7) > 0.5)

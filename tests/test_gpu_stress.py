@@ -410,3 +410,25 @@ def test_fused_gram_block_sparse_operators():
         want = np.einsum("bjv,blv->bjl", M, M)
         np.testing.assert_allclose(G[:, :m, :m], want, rtol=1e-9, atol=1e-10 * max(np.abs(want).max(), 1e-300),
                                    err_msg=tag)
+
+
+def test_latent_of_an_x_beyond_4_gib():
+    """K5 addresses the rows it stages by 32-bit byte offsets; an X of 4 GiB or more (here 240 x 2 300 000
+    doubles = 4.4 GB, made on the device) is walked in blocks of rows (plsr_latent).  Against torch's own
+    fp64 product."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    n, p, k, items = 240, 2_300_000, 12, 2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    X = torch.randn((n, p), dtype=torch.float64, device="cuda", generator=g)
+    vs = torch.randn((items, k, p), dtype=torch.float64, device="cuda", generator=g)
+    eng = ProjectionEngine(X)
+    Zt = torch.empty((items, k, n), dtype=torch.float64, device=eng.device)
+    nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device)
+    eng.latent_batch(vs, n, Zt, nsq)
+    want = torch.matmul(vs, X.t())
+    scale = float(want.abs().max())
+    assert float((Zt - want).abs().max()) <= 1e-11 * scale
+    assert torch.allclose(nsq, (vs * vs).sum(-1), rtol=1e-11)
+    del X, vs, want
+    torch.cuda.empty_cache()

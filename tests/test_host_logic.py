@@ -153,3 +153,30 @@ def test_degenerate_guard_matches_full_test():
     rows = rs.randint(0, 5, size=(300, 5))
     rows[7, :4] = 2
     assert np.array_equal(cf.degenerate_guard(Yb, co)(rows), cf.any_group_std_zero(Yb[rows], co))
+
+
+def test_workspace_queries_refuse_what_the_calls_refuse(lib):
+    """The kernels that address rows by 32-bit byte offsets: their workspace queries must return 0 exactly
+    for the shapes the calls would refuse, so that the engine's fallbacks are taken before anything is
+    launched (rows p apart, as the engine passes them).  plsr_latent walks an X of 4 GiB or more in blocks
+    of rows instead of refusing it."""
+    # K5: X = 240 x 2.3 M doubles = 4.4 GB -> served (row blocks); VS^T of one group beyond 4 GiB -> refused
+    assert lib.plsr_latent_workspace_bytes(240, 12, 10, 2_300_000) > 0
+    assert lib.plsr_latent_workspace_bytes(120, 48, 4, 4_600_000) > 0
+    assert lib.plsr_latent_workspace_bytes(240, 12, 10, 50_000_000) == 0          # 12 x 50 M x 8 B >= 4 GiB
+    assert lib.plsr_latent_workspace_bytes(240, 12, 10, 40_000_000) == 0          # fewer than 16 rows per block
+    # K4a / K4b: the result stores' lane offsets span 13 rows of VS^T
+    cells = (ctypes.c_int32 * 3)(0, 20, 40)
+    z = (ctypes.c_int32 * 2)(1, 1)
+    lo = (ctypes.c_int32 * 2)(0, 20)
+    hi = (ctypes.c_int32 * 2)(20, 40)
+    assert lib.plsr_item_agg_workspace_bytes(40, 40, 16, cells, z, lo, hi, 2, 8, 200_000, 1, 0) > 0
+    assert lib.plsr_item_agg_workspace_bytes(40, 40, 16, cells, z, lo, hi, 2, 8, 42_000_000, 1, 0) == 0
+    assert lib.plsr_item_beh_workspace_bytes(40, 40, 8, 16, cells, lo, hi, 2, 8, 200_000, 1) > 0
+    assert lib.plsr_item_beh_workspace_bytes(40, 40, 8, 16, cells, lo, hi, 2, 8, 42_000_000, 1) == 0
+    # K2s: 32-bit row offsets into X
+    rows = (ctypes.c_int32 * 4)(10, 10, 10, 10)
+    assert lib.plsr_split_gram_workspace_bytes(40, 200_000, 200_000, 8, rows, 4, 4, 0, 64, 5) > 0
+    assert lib.plsr_split_gram_workspace_bytes(240, 2_300_000, 2_300_000, 8, rows, 4, 4, 0, 64, 5) == 0
+    assert lib.plsr_split_gram_workspace_bytes(40, 200_000, 200_000, 9, rows, 4, 4, 0, 72, 5) == 0    # b > 8
+    assert lib.plsr_split_gram_workspace_bytes(40, 8, 8, 8, rows, 4, 4, 0, 64, 5) == 0               # p < 16
