@@ -26,7 +26,41 @@ def _stream():
 # scratch one batch may use (bytes); PLSR_WORK_LIMIT_GIB overrides the default
 DEFAULT_WORK_LIMIT = int(float(os.environ.get("PLSR_WORK_LIMIT_GIB", "24")) * (1 << 30))
 
+# host arrays of this size range are uploaded through recycled page-locked staging buffers (ProjectionEngine.dev);
+# PLSR_PIN_UPLOADS=0 switches that off (measurement knob of microbench/cfg3_perm_bimodal2.py)
+PIN_UPLOAD_MIN, PIN_UPLOAD_MAX = ((64 << 10), (8 << 20)) if os.environ.get("PLSR_PIN_UPLOADS", "1") != "0" else (1, 0)
+
 _SIDE_STREAMS = {}
+_STAGING = {}          # (device, size class) -> list of [page-locked byte buffer, event of its last upload]
+
+
+def _staged_upload(a, dtype, device):
+    """Device copy (as `dtype`) of the NumPy array `a` through a page-locked staging buffer, enqueued on the
+    current stream.  The buffers are a process-wide ring per power-of-two size class, reused once the upload
+    that last read them has finished (an event), so that after the first few calls nothing is page-locked
+    any more -- allocating a page-locked buffer is itself a page-table update (tens of milliseconds for MBs).
+    The host copy into the buffer is NumPy's (one thread: torch's copy_ spins up its OpenMP team, which
+    under the per-batch host work of the rb bootstrap cost 10 ms per call)."""
+    np_dtype = torch.empty(0, dtype=dtype).numpy().dtype
+    nbytes = a.size * np_dtype.itemsize
+    cls = 1 << max(nbytes - 1, 1).bit_length()
+    ring = _STAGING.setdefault((str(device), cls), [])
+    slot = next((s for s in ring if s[1].query()), None)
+    if slot is None:
+        if len(ring) >= 8:
+            slot = ring[0]
+            slot[1].synchronize()
+        else:
+            buf = torch.empty(cls, dtype=torch.uint8, pin_memory=True)
+            slot = [buf, torch.cuda.Event(), buf.numpy()]
+            ring.append(slot)
+    if slot is not ring[-1]:                      # least recently used first
+        ring.remove(slot)
+        ring.append(slot)
+    np.copyto(slot[2][:nbytes].view(np_dtype).reshape(a.shape), a, casting="unsafe")
+    t = slot[0][:nbytes].view(dtype).view(a.shape).to(device, non_blocking=True)
+    slot[1].record(torch.cuda.current_stream())
+    return t
 
 
 def _side_stream(device, name):
@@ -134,14 +168,25 @@ class ProjectionEngine:
         if a is None:
             return None
         if isinstance(a, np.ndarray):
-            src = torch.from_numpy(np.ascontiguousarray(a))
-            if src.dtype != dtype:
-                src = src.to(dtype)
             if self._h2d is None:
                 self._h2d = _side_stream(self.device, "h2d")
             cur = torch.cuda.current_stream()
+            staged = PIN_UPLOAD_MIN <= a.size * torch.empty(0, dtype=dtype).element_size() <= PIN_UPLOAD_MAX
+            if not staged:
+                src = torch.from_numpy(np.ascontiguousarray(a))
+                if src.dtype != dtype:
+                    src = src.to(dtype)
             with torch.cuda.stream(self._h2d):
-                t = src.to(self.device)
+                if staged:
+                    # mid-sized per-batch tables (behaviour z-scores, operator rows, index tables) go through a
+                    # recycled page-locked staging buffer (_staged_upload): copied straight from fresh
+                    # pageable memory, the runtime page-locks the caller's pages for the transfer,
+                    # i.e. updates the GPU's page tables under whatever kernel is running -- the first
+                    # projection launch of a phase then took 35-50 ms instead of 19 (config 3's "bimodal"
+                    # permutation time)
+                    t = _staged_upload(a, dtype, self.device)
+                else:
+                    t = src.to(self.device)
             cur.wait_stream(self._h2d)
             t.record_stream(cur)
             return t
