@@ -642,6 +642,9 @@ __global__ __launch_bounds__(64, (NK >= 16 || (DUMP && NK >= 12)) ? 1 : 2) void 
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       if (h >= nh) continue;
+#if PLSR_ABLATE & 2048                   // dev: no T product (and none of its cell-mean reads)
+      continue;
+#endif
       // T[cell 4 h + i][column 4 b + jj] lands at lane 16 i + 4 b + jj = (g = i, col).
       // Four independent accumulation chains (one per voxel tile): a single chain of
       // sixteen dependent 4x4x4 MFMAs would expose the MFMA latency sixteen times.
@@ -684,9 +687,16 @@ __global__ __launch_bounds__(64, (NK >= 16 || (DUMP && NK >= 12)) ? 1 : 2) void 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+#if PLSR_ABLATE & 512                    // dev: no second moment at all
+        (void)s2;
+#elif PLSR_ABLATE & 1024                 // dev: plain LDS stores instead of the atomics (wrong sums)
+        s2[(4 * nt + r) * 64] = acc[nt][r] * acc[nt][r];
+#else
         __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(s2 + (4 * nt + r) * 64),
                                             acc[nt][r] * acc[nt][r]);
+#endif
+      }
     }
     if (DUMP) {
       const int64_t b = (int64_t)(t - j * A.tpl) * 16 + col;
