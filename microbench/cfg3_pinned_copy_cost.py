@@ -11,7 +11,7 @@ np.random.seed(1234)
 res = plspy_amd.PLS(X, [20, 20], 3, Y=Y, num_perm=0, num_boot=0, pls_method="rb")
 U, s, V = res.V, res.s.copy(), res.U
 eng = E.ProjectionEngine(X)
-for thr in (32 << 20, 1 << 60, 32 << 20, 1 << 60):
+for thr in (32 << 20, 1 << 60, 32 << 20, 1 << 60):   # pageable (pre-faulted) results / page-locked views
     E.PINNED_COPY_BYTES = thr
     ts = []
     for _ in range(3):

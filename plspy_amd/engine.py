@@ -85,30 +85,52 @@ class _Lane:
         self.frag = None
 
 
-# fetch_async results of at least this many bytes are copied out of their page-locked buffers by get(): a
-# result object that keeps them (V, R, std_errs: 77 MB each at config 3) would otherwise keep that much
-# page-locked host memory for as long as it lives; smaller arrays stay views (the copy would cost the public
-# call at config 2 about a millisecond of its nine)
+# fetch_async results of at least this many bytes do not stay in page-locked memory: a result object that keeps them
+# (V, R, std_errs: 77 MB each at config 3) would otherwise keep that much page-locked host memory for as long as
+# it lives.  They are downloaded straight into a pageable array whose pages a helper thread touches while the
+# device still works (a copy out of the page-locked buffer cost 15 ms of config 3's 200 ms bootstrap phase, most of
+# it the page faults of the fresh array).  Smaller results stay views of recycled page-locked buffers.
 PINNED_COPY_BYTES = 32 << 20
 
 
-class _Fetch:
-    """Pending device -> pinned-host copies (ProjectionEngine.fetch_async)."""
+class _Prefault:
+    """A pageable result array whose pages are touched by a helper thread (ctypes.memset: no GIL)."""
 
-    def __init__(self, host, done):
-        self._host, self._done = host, done
+    def __init__(self, shape, dtype):
+        import threading
+        self.array = np.empty(shape, dtype=dtype)
+        self._th = threading.Thread(target=ctypes.memset, args=(self.array.ctypes.data, 0, self.array.nbytes))
+        self._th.start()
+
+    def ready(self):
+        self._th.join()
+        return self.array
+
+
+class _Fetch:
+    """Pending device -> host copies (ProjectionEngine.fetch_async).  Entries are either page-locked host
+    tensors with their copy in flight, or (device tensor, pre-faulted pageable array) pairs that are copied
+    at get() time, when the producing kernels have finished."""
+
+    def __init__(self, host, done, stream):
+        self._host, self._done, self._stream = host, done, stream
 
     def get(self, copy=None):
-        """NumPy arrays of the fetched tensors.  copy=None: arrays of PINNED_COPY_BYTES or more are copied into
-        pageable memory, smaller ones are views of the page-locked buffers (recycled by torch's caching host
-        allocator once dropped); True / False: all / none."""
+        """NumPy arrays of the fetched tensors.  Results of PINNED_COPY_BYTES or more are fresh pageable arrays;
+        smaller ones are views of page-locked buffers (recycled by torch's caching host allocator once dropped)
+        unless copy=True."""
         self._done.synchronize()
         out = []
         for h in self._host:
+            if isinstance(h, tuple):
+                t, pre = h
+                dst = pre.ready()
+                with torch.cuda.stream(self._stream):
+                    torch.from_numpy(dst).copy_(t)         # (pageable destination: the call returns when it is done)
+                out.append(dst)
+                continue
             a = h.numpy()
-            if copy or (copy is None and a.nbytes >= PINNED_COPY_BYTES):
-                a = np.array(a)
-            out.append(a)
+            out.append(np.array(a) if copy else a)
         return out
 
 
@@ -467,7 +489,8 @@ class ProjectionEngine:
         """Start copying device tensors into page-locked host memory on the download stream
         (behind everything enqueued on the current stream so far).  Returns a handle whose
         ``get()`` waits for these copies only and returns NumPy arrays (views of the pinned
-        buffers, which torch's caching host allocator recycles once the arrays are dropped).
+        buffers, which torch's caching host allocator recycles once the arrays are dropped; tensors of
+        PINNED_COPY_BYTES or more: fresh pageable arrays, pre-faulted meanwhile, see _Fetch).
         A `.cpu()` instead would block the host until the whole current stream has drained and
         move the data through a pageable staging copy."""
         if self._d2h is None:
@@ -479,13 +502,16 @@ class ProjectionEngine:
         with torch.cuda.stream(self._d2h):
             self._d2h.wait_event(ev)
             for t in tensors:
+                t.record_stream(self._d2h)
+                if t.numel() * t.element_size() >= PINNED_COPY_BYTES:
+                    host.append((t, _Prefault(tuple(t.shape), torch.empty(0, dtype=t.dtype).numpy().dtype)))
+                    continue
                 h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
                 h.copy_(t, non_blocking=True)
-                t.record_stream(self._d2h)
                 host.append(h)
             done = torch.cuda.Event()
             done.record(self._d2h)
-        return _Fetch(host, done)
+        return _Fetch(host, done, self._d2h)
 
     # -- K2: Gram / thin SVD -------------------------------------------------
     def gram_phase(self, rows, gather=None):

@@ -14,13 +14,13 @@ timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 > "$out/bench.log" 2>&1
 grep '^{' "$out/bench.log" | tail -1 > "$out/${tag}_bench.json"
 echo "[collect] kernel trace + stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
-    python3 bench.py --steps 40 --warmup 5 --no-cpu > "$out/stats.log" 2>&1 || exit 1
+    python3 bench.py --steps 40 --warmup 5 --no-cpu --no-pls-call --no-ceiling > "$out/stats.log" 2>&1 || exit 1
 echo "[collect] PMC pass 1 (FETCH_SIZE)"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o bench -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu > "$out/pmc_fetch.log" 2>&1 || exit 1
+    python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pls-call --no-ceiling > "$out/pmc_fetch.log" 2>&1 || exit 1
 echo "[collect] PMC pass 2 (WRITE_SIZE)"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o bench -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu > "$out/pmc_write.log" 2>&1 || exit 1
+    python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pls-call --no-ceiling > "$out/pmc_write.log" 2>&1 || exit 1
 for c in 3 4 5 6; do
   echo "[collect] config $c"
   timeout -k 10 400 python3 bench_configs.py --config $c > "$out/cfg$c.log" 2>&1 || exit 1
