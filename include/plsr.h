@@ -418,6 +418,36 @@ int plsr_split_gram(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
                     double *d_rownorm, void *d_work, size_t work_bytes, void *stream);
 
 /*
+ * The ROWS variant of K2s: the same cell description, but the item's (un-normalised) cross-block rows themselves
+ * are the result -- d_R [items][m][ldv] in logical row order -- with their squared norms over all voxels,
+ * d_rowsq [items][rowsq_stride].  First pass of the multiblock bootstrap (bootstrap_permutation.py:547-553, :610;
+ * class_functions.py:454-516 without the row normalisation): the rows of X a bootstrap sample draws are read by
+ * index (repeats and all), per cell; plsr_rows_project then normalises, projects and accumulates the moments.
+ */
+size_t plsr_split_rows_workspace_bytes(int32_t n, int64_t ldx, int64_t p, int32_t b, const int32_t *cell_rows,
+                                       int32_t nq, int32_t nbq, int32_t ktask, int32_t m, int32_t items);
+int plsr_split_rows(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_xsrc,
+                    const int32_t *d_ysrc, int32_t nz, const double *d_Y, int32_t b, const int32_t *cell_rows,
+                    int32_t nq, int32_t nbq, const double *d_Wc, int32_t ktask, const int32_t *row_cell,
+                    const int32_t *row_sub, int32_t m, int32_t items, double *d_R, int64_t ldv, double *d_rowsq,
+                    int64_t rowsq_stride, void *d_work, size_t work_bytes, void *stream);
+
+/*
+ * K4m: the second pass of the multiblock bootstrap as a stream over the first pass's products
+ * (class_functions.py:503-505, bootstrap_permutation.py:610, :620, :695).  plsr_item_agg / plsr_item_fused, run
+ * with the UN-NORMALISED multiblock rows as operator, leave R_b = raw_b Z_b (kr x p) in d_R and the squared norms
+ * of its rows in d_rowsq; this call replaces R_b by
+ *     VS_b^T[j][v] = sum_r d_U[r][j] / sqrt(d_rowsq[b][r]) * R_b[r][v]        (rows 0 .. k - 1 of item b's block)
+ * in place (a row of norm 0 contributes 0) and adds the shifted moment sums of VS_b over the items to d_S1 / d_S2
+ * ([p][k], shift d_ref or none), as plsr_item_agg does.  d_R [items][kr][ldv], d_U [kr][k], k <= kr <= 48,
+ * kr * ldv * 8 < 4 GiB (the query returns 0 otherwise; assumes ldv = p).
+ */
+size_t plsr_rows_project_workspace_bytes(int32_t kr, int32_t k, int32_t items, int64_t p, int32_t want_moments);
+int plsr_rows_project(double *d_R, int64_t ldv, int64_t p, int32_t items, int32_t kr, const double *d_rowsq,
+                      int64_t rowsq_stride, const double *d_U, int32_t k, const double *d_ref, double *d_S1,
+                      double *d_S2, void *d_work, size_t work_bytes, void *stream);
+
+/*
  * ---- F4: the upstream feed, X built on the device ---------------------------------
  * plspy/io/io.py:427-460 (apply_mask_matrices: `m[np.broadcast_to(mask, m.shape)]` -- for every
  * time point the voxels the mask selects, in C order) and :680-698 (concat_flatten_all_groups:

@@ -63,6 +63,12 @@ SIGNATURES = {
     "plsr_split_gram_workspace_bytes": (c_sz, [c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32]),
     "plsr_split_gram": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp,
                                 c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "plsr_split_rows_workspace_bytes": (c_sz, [c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "plsr_split_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp,
+                                c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "plsr_rows_project_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64, c_i32]),
+    "plsr_rows_project": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                  c_sz, c_vp]),
     "plsr_apply_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "plsr_scale_project_rows": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "plsr_latent_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),

@@ -704,6 +704,28 @@ class _ResampleTestPLS(ResampleTest):
                 scaled = U[None] / rownorm[:, :, None]
             return np.swapaxes(scaled, 1, 2) @ A                      # (r,j,k)(r,k,i) -> r,j,i
 
+        # the same items as cells of gathered rows (engine.split_rows): behaviour cells first (group x bscan
+        # condition: rows brows[bi] of X with rows bi of Ybscan), then the task cells (group x condition: rows ti),
+        # whose sums give the task rows -- the mean-centring operator is constant inside a cell
+        bounds_t = cf.cell_bounds(co)
+        Wcell = W[:, bounds_t[:-1]]
+        cells_ok = self._C is None and np.array_equal(W, np.repeat(Wcell, np.diff(bounds_t), axis=1))
+        row_cell, row_sub = [], []
+        for g in range(ng):
+            for r in range(per):
+                row_cell.append(-1 if r < nc else g * nbs + (r - nc) // b)
+                row_sub.append(g * nc + r if r < nc else (r - nc) % b)
+        ncb = len(bounds_b) - 1
+        Wc = np.concatenate((np.zeros((ng * nc, ncb)), Wcell), axis=1)
+
+        def cells_fn(a, z):
+            if not cells_ok:
+                return None, None
+            tb, bb = ti[lo:hi][a:z], bi[lo:hi][a:z]
+            return dict(xsrc=np.concatenate((brows[bb], tb), axis=1), ysrc=np.concatenate((bb, np.zeros_like(tb)), axis=1),
+                        cell_rows=[int(x) for x in np.diff(bounds_b)] + [int(x) for x in np.diff(bounds_t)], nbq=ncb,
+                        Wc=Wc, row_cell=row_cell, row_sub=row_sub), Yb
+
         cnt = hi - lo
         LVc = np.empty((cnt, (len(bounds_b) - 1) * b, k))
         Td = np.empty((cnt, co.size, k))
@@ -726,7 +748,8 @@ class _ResampleTestPLS(ResampleTest):
             spread_t.add(Td[a:z])
 
         res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n,
-                             on_batch=on_batch, project_on=U, after_enqueue=self._finalize_early(niter, ref))
+                             on_batch=on_batch, project_on=U, after_enqueue=self._finalize_early(niter, ref),
+                             cells_fn=cells_fn)
         std_errs, boot_ratios, (LVcorr, Tdistrib) = self._finish_items(res, [LVc, Td], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = (spread.std() if nranks == 1 else np.std(LVcorr, axis=0)) * z

@@ -126,6 +126,12 @@ struct SplitArgs {
   int32_t nx, csub;                    // voxel ranges per item: nx (<= 8, the XCDs) x csub
   int64_t ntile;                       // 16-voxel tiles
   double *Gp;                          // [items][nx * csub][NG][4][64]
+  // ROWS variant (split_rows: the rows themselves instead of their Gram)
+  double *R;                           // [items][m][ldv] the scaled rows, logical order
+  int64_t ldv;
+  int32_t m;
+  int16_t rowof[7 * 16];               // the kernel's row (tile * 16 + column) -> logical row, or -1
+  double *rowsq_part;                  // [items][nx * csub][MC * 16] squared norms of the kernel's rows over the range
 };
 
 
@@ -165,7 +171,9 @@ constexpr int split_gram_m2(int MC, int idx) {
 // independent MFMAs that fill the matrix pipe while the wave walks the dependent chain sum -> 4x4x4 MFMA ->
 // mean -> centred squares -> 4x4x4 MFMA -> rsqrt of the next tile (with one wave per SIMD nothing else would).
 // Scheduling barriers between the cells keep that interleave.
-template <int NTB, int NTO, int NTT, int CS, bool EXACT>
+// ROWS: the rows themselves are the result (stored in logical order, with their squared norms over the range) and no
+// Gram is formed -- the first pass of the multiblock bootstrap (engine.split_rows -> plsr_rows_project).
+template <int NTB, int NTO, int NTT, int CS, bool EXACT, bool ROWS = false>
 __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   constexpr int IP = SG_IP;
   constexpr int NP = NTB + NTO;                    // cell pairs
@@ -247,15 +255,29 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   selb[0] = kk == (col >> 3) ? 1.0 : 0.0;
   selb[1] = kk == 2 + (col >> 3) ? 1.0 : 0.0;
 
-  f64x4 G[NG];
+  f64x4 G[ROWS ? 1 : NG];
 #pragma unroll
-  for (int i = 0; i < NG; ++i) G[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < (ROWS ? 1 : NG); ++i) G[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // ROWS: per row tile, this lane's (column's) logical row as a byte offset into the item's block (-1: no such
+  // row) and the running sum of squares of its voxels
+  int64_t rowoff[ROWS ? MC : 1];
+  double rq[ROWS ? MC : 1];
+  if (ROWS) {
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+      const int lr = A.rowof[m * 16 + col];
+      rowoff[m] = lr < 0 ? -1 : ((int64_t)item * A.m + lr) * A.ldv * 8;
+      rq[m] = 0.0;
+    }
+  }
   // the previous tile's scaled rows (zero before the first) and the ones being formed.  (The loop body written
   // twice with the two sets' roles swapped, to save the copy at the end of a tile, spilled 700 bytes per lane:
   // the set being formed must sit in VGPRs for its scaling, the copy is what moves it to accumulator registers.)
-  f64x4 Da[MC], Db[MC];
+  f64x4 Da[ROWS ? 1 : MC], Db[MC];
 #pragma unroll
-  for (int m = 0; m < MC; ++m) Da[m] = Db[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int m = 0; m < MC; ++m) Db[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < (ROWS ? 1 : MC); ++m) Da[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
   // tile t covers voxels [16 t, 16 t + 16); the last one is read from p - 16 and masks what tile t - 1 had
   auto tile_v0 = [&](int64_t t) { return min(16 * t, A.p - 16); };
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   }
 
   // forms the scaled rows D of `tile` and adds the Gram of the previous tile's rows Dc
-  auto body = [&](int64_t tile, const f64x4 (&Dc)[MC], f64x4 (&D)[MC]) __attribute__((always_inline)) {
+  auto body = [&](int64_t tile, const f64x4 (&Dc)[ROWS ? 1 : MC], f64x4 (&D)[MC]) __attribute__((always_inline)) {
     const int64_t tcl = min(tile, t_hi - 1);
     const int64_t v0 = tile_v0(tcl);
     const bool vvalid = v0 + col >= 16 * tcl;
@@ -322,10 +344,13 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
             for (int s = 0; s < CS; ++s) xr[q * CS + s] = *(const double *)(bn + rl[(q * CS + s) * 64 + lane]);
           }
           // ---- this cell's share of the previous tile's Gram ----
+          if (!ROWS) {
 #pragma unroll
-          for (int j = q * GPC; j < (q + 1) * GPC && j < NGM; ++j) {
-            const int r = j / NG, idx = j % NG;
-            G[idx] = mfma_f64(Dc[split_gram_m1(MC, idx)][r], Dc[split_gram_m2(MC, idx)][r], G[idx]);
+            for (int j = q * GPC; j < (q + 1) * GPC && j < NGM; ++j) {
+              const int r = j / NG, idx = j % NG;
+              G[ROWS ? 0 : idx] = mfma_f64(Dc[ROWS ? 0 : split_gram_m1(MC, idx)][r], Dc[ROWS ? 0 : split_gram_m2(MC, idx)][r],
+                                           G[ROWS ? 0 : idx]);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -355,6 +380,23 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (ROWS) {
+      // the tile's rows leave: accumulator lane (column = row, kk), register r = voxel kk + 4 r.  A lane's four
+      // registers are four voxels 32 bytes apart... of ONE row: 8-byte stores, 32-byte runs per row and register
+      // (the L2 merges the four registers' runs of a row into its 128-byte line).  The shifted last tile does
+      // not store the voxels tile t - 1 already had.
+      char *Rb = (char *)A.R + (v0 + kk) * 8;
+#pragma unroll
+      for (int m = 0; m < MC; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double val = D[m][r];
+          const bool mine = v0 + kk + 4 * r >= 16 * tcl && tile < t_hi;
+          if (mine) rq[m] = fma(val, val, rq[m]);
+          if (mine && rowoff[m] >= 0) *(double *)(Rb + rowoff[m] + 32 * r) = val;
+        }
+      }
+    }
   };
 
   // The first tile's loads are drained before the loop: the compiler's wait-count pass merges the state at
@@ -365,11 +407,25 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   // one iteration more than there are tiles: the last one only has tile t_hi - 1's Gram to do (the rows it
   // forms from the re-read last tile are dropped)
   if (t_lo < t_hi) {
-    for (int64_t tile = t_lo; tile <= t_hi; ++tile) {
+    for (int64_t tile = t_lo; tile <= (ROWS ? t_hi - 1 : t_hi); ++tile) {
       body(tile, Da, Db);
+      if (!ROWS) {
 #pragma unroll
-      for (int m = 0; m < MC; ++m) Da[m] = Db[m];
+        for (int m = 0; m < (ROWS ? 1 : MC); ++m) Da[m] = Db[ROWS ? 0 : m];
+      }
     }
+  }
+  if (ROWS) {
+    // squared norms of this lane's rows over the range: the four kk lanes of a column together
+    double *o = A.rowsq_part + ((size_t)item * A.nx * A.csub + chunk) * MC * 16;
+#pragma unroll
+    for (int m = 0; m < MC; ++m) {
+      double x = rq[m];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      if (kk == 0) o[m * 16 + col] = x;
+    }
+    return;
   }
 
   double *out = A.Gp + ((size_t)item * A.nx * A.csub + chunk) * NG * 256;
@@ -434,6 +490,18 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(SplitReduceArgs A) {
   if (A.rownorm != nullptr)
     for (int l = threadIdx.x; l < A.mm; l += 256)
       A.rownorm[(size_t)item * A.mm + l] = l < A.m ? sqrt(smem[A.inv[l] * LD + A.inv[l]]) : 0.0;
+}
+
+// ROWS: d_rowsq[item][l] = sum over the ranges of the squared norm of the kernel's row that is logical row l
+__global__ __launch_bounds__(256) void split_rowsq_kernel(const double *part, int items, int nchunk, int MC, int m,
+                                                          int64_t stride, SplitReduceArgs inv, double *rowsq) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)items * m) return;
+  const int item = (int)(e / m), l = (int)(e % m);
+  const int at = inv.inv[l];
+  double acc = 0.0;
+  for (int c = 0; c < nchunk; ++c) acc += part[((size_t)item * nchunk + c) * MC * 16 + at];
+  rowsq[(int64_t)item * stride + l] = acc;
 }
 
 }  // namespace plsr

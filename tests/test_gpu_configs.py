@@ -291,8 +291,8 @@ def test_config4_planted_graded_spectrum():
 
 
 def test_config6_mb_bootstrap_full_size():
-    """Multiblock bootstrap (not a BASELINE config; SURVEY a12 on config 4's data): the two K4f passes
-    (row norms, projection) + K5 at n = 120, kr = 38."""
+    """Multiblock bootstrap (not a BASELINE config; SURVEY a12 on config 4's data): rows (K2s ROWS variant),
+    projection (K4m) + K5x at n = 120, kr = 38."""
     from plspy_amd.bootstrap_permutation import ResampleTest
     co = np.array([[20] * 3, [20] * 3])
     X = np.random.RandomState(0).randn(120, 200_000)
@@ -300,23 +300,37 @@ def test_config6_mb_bootstrap_full_size():
     bscan = [1, 2]
     obs = orc.observed("mb", X, co, Y=Y, mctype=0, bscan=bscan)
     U, s, V = obs["U"], obs["s"], obs["V"]
-    nboot = 40
+    nboot = 14
     np.random.seed(5)
+    from plspy_amd.engine import ProjectionEngine
+    eng = ProjectionEngine(X)
     rt = ResampleTest._create("mb", X, Y, U, s.copy(), V, co, 0, nperm=0, nboot=nboot, bscan=bscan,
                               Xbscan=obs["Xbscan"], Ybscan=obs["Ybscan"], lvcorrs_orig=obs["lvcorrs"],
-                              Tvsc_orig=obs["Tvsc_orig"])
+                              Tvsc_orig=obs["Tvsc_orig"], engine=eng)
+    # round 3: the un-normalised rows from the two-stage kernel (plsr_split_rows), the projection as a stream
+    # over them (plsr_rows_project)
+    assert eng.last_item_kernel == "rows+project", eng.last_item_kernel
     draws = rt.boot_debug_dict["indices"]
     n = 120
     ti, bi = draws[:, :n], draws[:, n:]
     live = s > 1e-10 * s.max()
-    for b in (0, nboot - 1):
+    sub = _subset(200_000, 200)
+    VSsub = []
+    for b in range(nboot):
         M = orc.create_multiblock(X[ti[b]], co, "mb", bscan, 0, Xbscan=obs["Xbscan"][bi[b]],
                                   Ybscan=obs["Ybscan"][bi[b]])       # :610
+        VSsub.append(M[:, sub].T @ U)                                 # :620 on a voxel subset (rows normalised over ALL voxels)
+        if b not in (0, nboot - 1):
+            continue
         Vh = orc.normalize(M.T @ U)                                   # :620, :623
         lc = orc.compute_corr(obs["Xbscan"][bi[b]] @ Vh, obs["Ybscan"][bi[b]], co[:, bscan])
         assert_close(rt.LVcorr[b][:, live], lc[:, live], 1e-8, 1e-11, f"mb LVcorr[{b}]")
         Td = orc.group_condition_means(orc.calculate_smeanmat(X[ti[b]], co, 0) @ Vh, co)
         assert_close(rt.boot_debug_dict["Tdistrib"][b][:, live], Td[:, live], 1e-8, 1e-11, f"mb Tdistrib[{b}]")
+    # :695, :700: np.std of every bootstrap's projection, on the subset
+    want_sd = np.std(np.array(VSsub), axis=0)
+    assert_close(rt.std_errs[sub][:, live], want_sd[:, live], 1e-8, 1e-12, "mb std_errs")
+    assert_close(rt.boot_ratios[sub][:, live], ((V * s)[sub] / want_sd)[:, live], 1e-7, 1e-9, "mb boot_ratios")
     assert np.isfinite(rt.std_errs).all()
 
 

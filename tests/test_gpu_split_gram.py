@@ -120,3 +120,78 @@ def test_split_gram_declines_what_it_cannot_serve():
     assert eng.split_gram(item["cells"], Y) is None
     G, _ = sh._grams(eng, item, np.arange(item["S"]))     # ... and the caller falls back to the fused Gram
     assert G.shape[0] == item["S"]
+
+
+def _numpy_rows(X, Y, cells, item):
+    lo = np.concatenate(([0], np.cumsum(cells["cell_rows"])))
+    xs, ys = cells["xsrc"][item], cells["ysrc"][item]
+    beh, sums = [], []
+    for q, (a, e) in enumerate(zip(lo[:-1], lo[1:])):
+        Xc = X[xs[a:e]]
+        if q < cells["nbq"]:
+            beh.append(_zs(Y[ys[a:e]]).T @ _zs(Xc))
+        sums.append(Xc.sum(0))
+    task = cells["Wc"] @ np.array(sums) if cells["Wc"] is not None else None
+    return np.array([beh[rc][rs] if rc >= 0 else task[rs] for rc, rs in zip(cells["row_cell"], cells["row_sub"])])
+
+
+@pytest.mark.parametrize("case", [
+    # groups, conditions, behaviours, bscan, p, items
+    ((20, 20), 3, 8, [1, 2], 4103, 5),               # config 6's cell structure: the exact instance
+    ((6, 5), 3, 2, [0, 2], 333, 4),                  # ragged cells
+    ((9,), 2, 3, [1], 130, 3),                       # one group
+])
+def test_split_rows_of_bootstrap_samples(case):
+    """The ROWS variant (plsr_split_rows) on bootstrap-shaped items -- rows drawn WITH replacement inside their
+    cells, task and behaviour blocks drawn independently (bootstrap_permutation.py:547-553) -- against the
+    direct NumPy statement of the un-normalised multiblock rows and their norms; then plsr_rows_project on
+    top (normalise, project on U, moments)."""
+    import torch
+    from plspy_amd import class_functions as cf, operators
+    from plspy_amd.engine import ProjectionEngine
+    groups, nc, b, bscan, p, items = case
+    rs = np.random.RandomState(p + items)
+    co = np.array([[g] * nc for g in groups])
+    n = int(co.sum())
+    X = rs.randn(n, p) * (1 + rs.rand(1, p)) + rs.randn(1, p)
+    Yb_rows = np.flatnonzero(cf.bscan_mask(co, bscan))
+    Yb = rs.randn(len(Yb_rows), b)
+    bt, bb = cf.cell_bounds(co), cf.cell_bounds(co[:, bscan])
+    # with-replacement draws inside every cell (the reference draws subjects; any multiset will do here)
+    ti = np.concatenate([rs.randint(lo, hi, size=(items, hi - lo)) for lo, hi in zip(bt[:-1], bt[1:])], axis=1)
+    bi = np.concatenate([rs.randint(lo, hi, size=(items, hi - lo)) for lo, hi in zip(bb[:-1], bb[1:])], axis=1)
+    W = operators.mean_centre_operator(co, 0)
+    Wcell = W[:, bt[:-1]]
+    ng, nbs = len(groups), len(bscan)
+    per = nc + nbs * b
+    row_cell, row_sub = [], []
+    for g in range(ng):
+        for r in range(per):
+            row_cell.append(-1 if r < nc else g * nbs + (r - nc) // b)
+            row_sub.append(g * nc + r if r < nc else (r - nc) % b)
+    ncb = len(bb) - 1
+    cells = dict(xsrc=np.concatenate((Yb_rows[bi], ti), axis=1), ysrc=np.concatenate((bi, np.zeros_like(ti)), axis=1),
+                 cell_rows=[int(x) for x in np.diff(bb)] + [int(x) for x in np.diff(bt)], nbq=ncb,
+                 Wc=np.concatenate((np.zeros((ng * nc, ncb)), Wcell), axis=1), row_cell=row_cell, row_sub=row_sub)
+    eng = ProjectionEngine(X)
+    got = eng.split_rows(cells, Yb)
+    assert got is not None
+    R, rowsq = got
+    kr = ng * per
+    want = np.stack([_numpy_rows(X, Yb, cells, i) for i in range(items)])
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(R.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * scale)
+    np.testing.assert_allclose(rowsq.cpu().numpy()[:, :kr], (want ** 2).sum(-1), rtol=1e-10, atol=1e-20)
+    # second pass on top: VS = (U^T D^-1) R, shifted moments
+    U = np.linalg.qr(rs.randn(kr, kr))[0]
+    ref = rs.randn(p, kr)
+    S1 = torch.zeros((p, kr), dtype=torch.float64, device=eng.device)
+    S2 = torch.zeros_like(S1)
+    assert eng.rows_project(R, rowsq, U, ref=ref, S1=S1, S2=S2)
+    nrm = np.sqrt((want ** 2).sum(-1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.where(nrm > 0, 1.0 / nrm, 0.0)
+    VS = np.einsum("rj,br,brv->bjv", U, inv, want)
+    np.testing.assert_allclose(R.cpu().numpy(), VS, rtol=1e-9, atol=1e-11 * np.abs(VS).max())
+    d = np.transpose(VS, (0, 2, 1)) - ref
+    np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-10 * items)

@@ -432,3 +432,38 @@ def test_latent_of_an_x_beyond_4_gib():
     assert torch.allclose(nsq, (vs * vs).sum(-1), rtol=1e-11)
     del X, vs, want
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape", [
+    # kr = k, p, items
+    (38, 2001, 9), (5, 130, 3), (16, 64, 17), (33, 777, 4), (48, 515, 6), (1, 31, 2),
+])
+def test_rows_project_matches_numpy(shape):
+    """K4m (plsr_rows_project): VS_b = (U^T D_b^-1) R_b in place + shifted moment sums, against NumPy; a row of
+    norm 0, voxel counts off the tile, k off the 16-row tile."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    kr, p, items = shape
+    rs = np.random.RandomState(kr + p)
+    eng = ProjectionEngine(rs.randn(4, p))
+    R = rs.randn(items, kr, p) * np.exp(rs.randn(items, kr, 1))
+    rowsq = (R ** 2).sum(-1) * (0.5 + rs.rand(items, kr))      # (any positive numbers: the kernel takes them as given)
+    if kr > 2:
+        rowsq[0, 1] = 0.0                                        # a row of norm 0 contributes 0
+    U = np.linalg.qr(rs.randn(kr, kr))[0]
+    ref = rs.randn(p, kr)
+    d_R = eng.dev(R.copy())
+    k16 = (kr + 15) // 16 * 16
+    d_sq = torch.zeros((items, k16), dtype=torch.float64, device=eng.device)
+    d_sq[:, :kr] = eng.dev(rowsq)
+    S1 = torch.zeros((p, kr), dtype=torch.float64, device=eng.device)
+    S2 = torch.zeros_like(S1)
+    assert eng.rows_project(d_R, d_sq, U, ref=ref, S1=S1, S2=S2)
+    with np.errstate(divide="ignore"):
+        inv = np.where(rowsq > 0, 1.0 / np.sqrt(rowsq), 0.0)
+    want = np.einsum("rj,br,brv->bjv", U, inv, R)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(d_R.cpu().numpy(), want, rtol=1e-11, atol=1e-12 * scale)
+    d = np.transpose(want, (0, 2, 1)) - ref
+    np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-10, atol=1e-11 * scale * items)
+    np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-10, atol=1e-11 * scale ** 2 * items)
