@@ -283,6 +283,7 @@ def _cell_row_map(cells, k, b):
 # A singular value whose square is below this fraction of the largest one is refined (see _decompose):
 # the eigen-decomposition of a Gram loses eps (s_1 / s_i)^2 of relative accuracy, 2e-11 at this ratio
 REFINE_RATIO = 1e-5
+DECOMPOSE_BATCHES = 1          # (2 measured +1 %, 4 -4 %, 8 -18 %: smaller launches cost what the overlap gains, microbench/split_batches.py)
 
 
 def _grams(engine, item, sel):
@@ -372,33 +373,40 @@ def _decompose(engine, item, contrasts=None, second=True):
     lo, hi = dist.shard_bounds(S, rank, nranks)
     mm = (2 * k + 15) // 16 * 16
     eps = np.finfo(float).eps
-    if hi > lo:
-        G, rown = _grams(engine, item, np.arange(lo, hi))
-    else:
-        G, rown = torch.zeros((0, mm, mm), dtype=torch.float64, device=engine.device), None
+    # The shard's items go to the device in a few batches, all enqueued before the host waits for anything: the
+    # host's share of batch i (H, the refinement test) then runs beside the kernels of batches i + 1 ...
+    sel_all = np.arange(lo, hi)
+    batches = [b for b in np.array_split(sel_all, max(1, min(DECOMPOSE_BATCHES, len(sel_all) // 256))) if len(b)]
     if contrasts is not None:
-        (Gall,), _ = dist.exchange([G[:, :2 * k, :2 * k].contiguous()], [], S)
+        Gs = [_grams(engine, item, sel)[0][:, :2 * k, :2 * k].contiguous() for sel in batches]
+        G = torch.cat(Gs) if Gs else torch.zeros((0, 2 * k, 2 * k), dtype=torch.float64, device=engine.device)
+        (Gall,), _ = dist.exchange([G], [], S)
         Gall = Gall.cpu().numpy()
         C = np.asarray(contrasts, dtype=float)
         s1 = np.sqrt(np.einsum("kq,skl,lq->sq", C, Gall[:, :k, :k], C))
         return None, s1, None, None, C.T @ Gall[:, :k, k:] @ C
-    if hi > lo:
+    pending = []
+    for sel in batches:
+        G, rown = _grams(engine, item, sel)
         e1, v1 = engine.eigh(G, 0, k)
         want = [e1, v1, G[:, :k, k:2 * k].contiguous()] + ([rown] if rown is not None else [])
         if second:
             want += list(engine.eigh(G, k, k))
-        got = engine.fetch_async(want)
+        pending.append((sel, engine.fetch_async(want), rown is not None))
+    out = [[] for _ in range(5)]
+    if pending:
         nn1, nn2 = _structural_nulls(item)           # (host work beside the kernels)
-        got = [np.array(a) for a in got.get()]
+    for sel, fetch, has_rown in pending:
+        got = [np.array(a) for a in fetch.get()]
         e1, v1, G12 = got[:3]
-        rest = got[3:4] if rown is not None else []
+        rest = got[3:4] if has_rown else []
         if second:
             e2, v2 = got[-2:]
             H = np.transpose(v1, (0, 2, 1)) @ G12 @ v2
         else:
             e2, v2 = np.zeros_like(e1), np.broadcast_to(np.eye(k), v1.shape).copy()
             H = np.transpose(v1, (0, 2, 1)) @ G12
-        tol = np.full((hi - lo, 1), 64 * k * eps)
+        tol = np.full((len(sel), 1), 64 * k * eps)
         # graded spectra: the smallest structurally live eigenvalue against the largest
         ratio = e1[:, max(k - nn1 - 1, 0)] / np.maximum(e1[:, 0], np.finfo(float).tiny)
         if second:
@@ -408,14 +416,17 @@ def _decompose(engine, item, contrasts=None, second=True):
             deep = ratio[need] < 1e-9
             for grp, passes in ((need[~deep], 1), (need[deep], 2)):
                 if grp.size:
-                    r = _refine(engine, item, lo + grp, v1[grp], v2[grp], rest[0][grp] if rest else None, passes,
-                                second)
+                    r = _refine(engine, item, sel[grp], v1[grp], v2[grp], rest[0][grp] if rest else None, passes, second)
                     e1[grp], v1[grp], e2[grp], v2[grp], H[grp] = r
             tol[need] = (4 * k * eps) ** 2
         for e, nn in ((e1, nn1), (e2, nn2)):
             e[e <= tol * np.maximum(e[:, :1], 0.0)] = 0.0
             if nn:
                 e[:, k - nn:] = 0.0
+        for acc, a in zip(out, (e1, v1, e2, v2, H)):
+            acc.append(a)
+    if pending:
+        e1, v1, e2, v2, H = (np.concatenate(acc) for acc in out)
     else:
         e1, v1, e2, v2, H = (np.zeros(shape) for shape in ((0, k), (0, k, k), (0, k), (0, k, k), (0, k, k)))
     if nranks > 1:

@@ -195,3 +195,55 @@ def test_split_rows_of_bootstrap_samples(case):
     np.testing.assert_allclose(R.cpu().numpy(), VS, rtol=1e-9, atol=1e-11 * np.abs(VS).max())
     d = np.transpose(VS, (0, 2, 1)) - ref
     np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-10 * items)
+
+
+def test_split_gram_random_cell_structures():
+    """Random cell structures straight through engine.split_gram / split_rows (not through the split-half
+    drawing code): one to twenty cells of 1..20 rows, 1..8 behaviours, with and without task rows, rows
+    repeated inside cells, voxel counts off the tile -- every guarded instance, against NumPy."""
+    from plspy_amd.engine import ProjectionEngine
+    rs = np.random.RandomState(2024)
+    served = 0
+    for trial in range(40):
+        n = int(rs.randint(8, 90))
+        p = int(rs.choice([16, 17, 130, 257, 1000]))
+        b = int(rs.randint(1, 9))
+        rmax = int(rs.choice([4, 12, 20]))
+        nbq = int(rs.randint(1, 7 if rmax > 12 else 11))
+        ntask = int(rs.randint(0, min(8, 20 - nbq) + 1))
+        ktask = int(rs.randint(1, 9)) if ntask else 0
+        cell_rows = [int(rs.randint(1, rmax + 1)) for _ in range(nbq + ntask)]
+        nz = sum(cell_rows)
+        items = int(rs.randint(1, 5))
+        X = rs.randn(n, p) * 2 + rs.randn(1, p)
+        X[:, 3] = -1.5                                         # a constant voxel
+        Y = rs.randn(n, b)
+        if b > 1:
+            Y[:, 1] = 0.25                                     # a constant behaviour
+        Wc = np.concatenate((np.zeros((ktask, nbq)), rs.randn(ktask, ntask)), axis=1) if ntask else None
+        row_cell = [q for q in range(nbq) for _ in range(b)] + [-1] * ktask
+        row_sub = [s for _ in range(nbq) for s in range(b)] + list(range(ktask))
+        perm = rs.permutation(len(row_cell))                   # any logical order of the rows
+        cells = dict(xsrc=rs.randint(0, n, size=(items, nz)), ysrc=rs.randint(0, n, size=(items, nz)),
+                     cell_rows=cell_rows, nbq=nbq, Wc=Wc, normalise=bool(trial % 2),
+                     row_cell=[row_cell[i] for i in perm], row_sub=[row_sub[i] for i in perm])
+        eng = ProjectionEngine(X)
+        tag = f"trial {trial}: n={n} p={p} b={b} cells={cell_rows} nbq={nbq} ktask={ktask}"
+        res = eng.split_gram(cells, Y)
+        rows = eng.split_rows(cells, Y)
+        if res is None:
+            assert rows is None or len(row_cell) <= 96, tag
+            continue
+        served += 1
+        m = len(row_cell)
+        G = res[0].cpu().numpy()
+        for it in range(items):
+            want = _numpy_gram(X, Y, cells, it)
+            assert_close(G[it, :m, :m], want, 1e-9, 1e-11 * max(np.abs(want).max(), 1e-300), tag)
+        if rows is not None:
+            R, rowsq = rows
+            wantR = np.stack([_numpy_rows(X, Y, cells, i) for i in range(items)])
+            np.testing.assert_allclose(R.cpu().numpy(), wantR, rtol=1e-9, atol=1e-11 * max(np.abs(wantR).max(), 1e-300),
+                                       err_msg=tag)
+            np.testing.assert_allclose(rowsq.cpu().numpy()[:, :m], (wantR ** 2).sum(-1), rtol=1e-9, atol=1e-18, err_msg=tag)
+    assert served >= 25, served

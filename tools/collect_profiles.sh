@@ -32,4 +32,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 echo "[collect] config 4 kernel stats"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats4" -o c4 -- \
     python3 bench_configs.py --config 4 > "$out/stats4.log" 2>&1 || exit 1
+echo "[collect] config 6 kernel stats"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats6" -o c6 -- \
+    python3 bench_configs.py --config 6 > "$out/stats6.log" 2>&1 || exit 1
 echo "[collect] done"

@@ -21,6 +21,7 @@ copy(f"{tag}_configs_3_4_5_single_gpu.jsonl", f"{tag}_configs_3_4_5_single_gpu.j
 copy("stats/*kernel_stats.csv", f"{tag}_kernel_stats.csv")
 copy("stats3/*kernel_stats.csv", f"{tag}_cfg3_kernel_stats.csv")
 copy("stats4/*kernel_stats.csv", f"{tag}_cfg4_kernel_stats.csv")
+copy("stats6/*kernel_stats.csv", f"{tag}_cfg6_kernel_stats.csv")
 
 pmc = collections.defaultdict(dict)
 for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
