@@ -128,7 +128,7 @@ def main():
             n, p, groups, nc = 64, 200_000, [16, 16], 2
         R = args.count or (5000 if args.config == 5 else 1000)
         X, _ = data(n, p)
-        res, t_all = timed(lambda: plspy_amd.PLS(X, groups, nc, num_perm=R, num_boot=R, pls_method="mct"))
+        res, t_all = timed(lambda: plspy_amd.PLS(X, groups, nc, num_perm=R, num_boot=R, pls_method="mct"), "pls_call")
         out.update(workload=f"mct X={n}x{p}, groups {groups} x {nc}, {R} perm + {R} boot via PLS()", seconds_total=t_all,
                    resamples_per_s_end_to_end=2 * R / t_all, s=res.s.tolist())
         # resampling phases alone (observed decomposition excluded)
