@@ -174,7 +174,8 @@ constexpr int split_gram_m2(int MC, int idx) {
 // ROWS: the rows themselves are the result (stored in logical order, with their squared norms over the range) and no
 // Gram is formed -- the first pass of the multiblock bootstrap (engine.split_rows -> plsr_rows_project).
 template <int NTB, int NTO, int NTT, int CS, bool EXACT, bool ROWS = false>
-__global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS && EXACT ? 2 : 1)))
+void split_gram_kernel(SplitArgs A) {
   constexpr int IP = SG_IP;
   constexpr int NP = NTB + NTO;                    // cell pairs
   constexpr int NQ = NP * IP;                      // cell slots
@@ -258,16 +259,19 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
   f64x4 G[ROWS ? 1 : NG];
 #pragma unroll
   for (int i = 0; i < (ROWS ? 1 : NG); ++i) G[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  // ROWS: per row tile, this lane's (column's) logical row as a byte offset into the item's block (-1: no such
-  // row) and the running sum of squares of its voxels
-  int64_t rowoff[ROWS ? MC : 1];
+  // ROWS: the byte offset of every kernel row's logical row in R (-1: no such row), a transpose patch, and per
+  // row tile the running sum of squares of this lane's (column's) voxels
+  int64_t *rofl = (int64_t *)(smem + NS * 32 + (BFREG ? 0 : (size_t)nbq * cs * 64));
+  double *tp = (double *)(rofl + (ROWS ? MC * 16 : 0));
   double rq[ROWS ? MC : 1];
   if (ROWS) {
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
-      const int lr = A.rowof[m * 16 + col];
-      rowoff[m] = lr < 0 ? -1 : ((int64_t)item * A.m + lr) * A.ldv * 8;
       rq[m] = 0.0;
+      if (lane < 16) {
+        const int lr = A.rowof[m * 16 + lane];
+        rofl[m * 16 + lane] = lr < 0 ? -1 : ((int64_t)item * A.m + lr) * A.ldv * 8;
+      }
     }
   }
   // the previous tile's scaled rows (zero before the first) and the ones being formed.  (The loop body written
@@ -381,20 +385,39 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ROWS) {
-      // the tile's rows leave: accumulator lane (column = row, kk), register r = voxel kk + 4 r.  A lane's four
-      // registers are four voxels 32 bytes apart... of ONE row: 8-byte stores, 32-byte runs per row and register
-      // (the L2 merges the four registers' runs of a row into its 128-byte line).  The shifted last tile does
-      // not store the voxels tile t - 1 already had.
-      char *Rb = (char *)A.R + (v0 + kk) * 8;
+      // The tile's rows leave.  In the accumulator a lane holds four voxels 32 bytes apart of ONE row: stored as
+      // they are, every store instruction touched sixteen 128-byte lines with 32 bytes each and the launch wrote at
+      // 1.9 TB/s (14 of its 32 us per item; without the stores: 18).  So a row tile goes through a per-wave LDS
+      // patch (16 x 18 doubles) and leaves as whole lines: lane l stores voxels 2 (l % 8), + 1 of row l / 8 (+ 8).
 #pragma unroll
       for (int m = 0; m < MC; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double val = D[m][r];
-          const bool mine = v0 + kk + 4 * r >= 16 * tcl && tile < t_hi;
+          const bool mine = v0 + kk + 4 * r >= 16 * tcl;
           if (mine) rq[m] = fma(val, val, rq[m]);
-          if (mine && rowoff[m] >= 0) *(double *)(Rb + rowoff[m] + 32 * r) = val;
+          tp[col * 18 + kk + 4 * r] = val;
         }
+        asm volatile("" ::: "memory");
+        typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = h * 8 + (lane >> 3), vp = 2 * (lane & 7);
+          const d2 pair = *(const d2 *)(tp + row * 18 + vp);
+          const int64_t ro = rofl[m * 16 + row];
+#if !(PLSR_ABLATE & 4096)                 // (dev: the ROWS variant without its stores)
+          if (ro >= 0) {
+            char *dst = (char *)A.R + ro + (v0 + vp) * 8;
+            if (v0 == 16 * tcl) {
+              *(d2 *)dst = pair;
+            } else {                       // the shifted last tile: only the voxels tile t - 1 did not have
+              if (v0 + vp >= 16 * tcl) *(double *)dst = pair.x;
+              if (v0 + vp + 1 >= 16 * tcl) *(double *)(dst + 8) = pair.y;
+            }
+          }
+#endif
+        }
+        asm volatile("" ::: "memory");
       }
     }
   };
@@ -436,8 +459,9 @@ __global__ __launch_bounds__(64) void split_gram_kernel(SplitArgs A) {
 }
 
 // LDS of a workgroup: row offsets of the instance's ns ring slots, then (generic instances) the stage-1 fragments
-inline size_t split_lds_bytes(int nbq, int cs, int ns, bool exact) {
-  return (size_t)ns * 64 * sizeof(uint32_t) + (exact ? 0 : (size_t)nbq * cs * 64 * sizeof(double));
+inline size_t split_lds_bytes(int nbq, int cs, int ns, bool exact, int rows_mc = 0) {
+  return (size_t)ns * 64 * sizeof(uint32_t) + (exact ? 0 : (size_t)nbq * cs * 64 * sizeof(double)) +
+         (rows_mc ? (size_t)rows_mc * 16 * sizeof(int64_t) + 16 * 18 * sizeof(double) : 0);
 }
 
 struct SplitReduceArgs {

@@ -72,7 +72,7 @@ bool split_plan(int32_t n, int64_t ldx, int64_t p, int32_t b, const int32_t *cel
     const int64_t want = (4096 + (int64_t)items * pl.nx - 1) / ((int64_t)items * pl.nx);
     pl.csub = (int)std::max<int64_t>(1, std::min<int64_t>(want, per_x / 64));
   }
-  pl.lds = split_lds_bytes(nbq, cs, pl.NQ * pl.CS, pl.exact);
+  pl.lds = split_lds_bytes(nbq, cs, pl.NQ * pl.CS, pl.exact, rows ? pl.MC : 0);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t o = off;
