@@ -258,6 +258,28 @@ int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const double *d_vst
                    int32_t k, double *d_Zt, double *d_nsq, void *d_work, size_t work_bytes, void *stream);
 
 /*
+ * K5i: d_L[b][j][i] = sum_v VS_b[j][v] X[d_idx[b][i]][v], i < m -- the latent scores of the SAMPLE,
+ * `_compute_X_latents(X_new, V_hat)` with X_new = X[inds] before the column normalisation
+ * (bootstrap_permutation.py:638, :646; class_functions.py:165-182).  A bootstrap sample of n rows holds
+ * about 0.63 n different rows: a small kernel lists them per item (ascending); a wave owns sixteen
+ * entries of the list and reads those rows from d_XB, a tile-major copy of X ([tile of 32 voxels][n]
+ * [32], voxels past p zero; plsr_latent_xb_bytes / plsr_latent_xb_prepare, once per X): one 32-byte
+ * load per lane = one 128-byte line per row and instruction, VS^T goes through LDS as in K5x; waves
+ * past an item's list only stage.  The chunk sum scatters the columns back to the sample's order.
+ * n <= 128, k <= 64.
+ * max_rows: the caller's bound on the number of different rows per item (<= n; it sets the workgroup
+ * size, one wave per sixteen); an item that exceeds it, or holds an index outside [0, n), comes back
+ * as NaN.  d_nsq as for plsr_latent.  vst_tiled != 0: d_vst is tile-major (see plsr_item_beh).
+ */
+size_t plsr_latent_xb_bytes(int32_t n, int64_t p);
+int plsr_latent_xb_prepare(const double *d_X, int64_t ldx, int64_t p, int32_t n, double *d_XB, void *stream);
+size_t plsr_latent_index_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p, int32_t m,
+                                         int32_t max_rows);
+int plsr_latent_index(const double *d_XB, int64_t p, int32_t n, const double *d_vst, int64_t ldv,
+                      int32_t vst_tiled, int32_t items, int32_t k, const int32_t *d_idx, int32_t m,
+                      int32_t max_rows, double *d_L, double *d_nsq, void *d_work, size_t work_bytes, void *stream);
+
+/*
  * ---- K0: a handful of operator rows applied to X ------------------------------
  * d_out (m x p, row stride ldo) = d_rows (m x n, row-major) @ X.  The observed
  * blocks of a PLS() call: _mean_centre / cell means as the operator W
@@ -349,7 +371,12 @@ int plsr_item_agg(const double *d_X, int64_t ldx, int64_t p, int32_t n, const in
  *          (their columns must sum to zero over a cell: the shift of X's z-score then drops out)
  *   d_U  : [ncell * b][k] left singular vectors, rows ordered (cell, behaviour)
  *   cell_lo / src_lo / src_hi : HOST arrays as in plsr_item_agg (an item that reads outside its
- *          ranges comes out as NaN); d_S1 / d_S2 / d_ref / d_vst as in plsr_item_fused
+ *          ranges comes out as NaN); d_S1 / d_S2 / d_ref / d_vst as in plsr_item_fused;
+ *          vst_tiled != 0: d_vst is written TILE-MAJOR, [items][ldv / 32][k][32] (ldv a multiple of 32:
+ *          a 32-voxel tile's k rows of 256 bytes side by side) -- the layout plsr_latent_index streams
+ *          (a workgroup's 64 voxels leave as two contiguous blocks of k x 256 bytes per item instead of
+ *          k pieces of 512 bytes 8 ldv apart, and a wave of the latent kernel reads its voxel range as one
+ *          contiguous block)
  * b <= 16, k <= 48, ncell <= 16, and (cells x k-steps of the longest cell) must fit one of the
  * register layouts (5 x 6, 8 x 4, 4 x 8, 2 x 16): plsr_item_beh_workspace_bytes returns 0 otherwise.
  */
@@ -359,8 +386,8 @@ size_t plsr_item_beh_workspace_bytes(int32_t n, int32_t nz, int32_t b, int32_t k
 int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_t *d_src, int32_t nz,
                   const int32_t *cell_lo, const int32_t *src_lo, const int32_t *src_hi, int32_t ncell,
                   const double *d_Yz, int32_t b, const double *d_U, int32_t items, int32_t k,
-                  const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv, void *d_work,
-                  size_t work_bytes, void *stream);
+                  const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv, int32_t vst_tiled,
+                  void *d_work, size_t work_bytes, void *stream);
 
 /*
  * Multiblock operator rows for plsr_item_fused, formed on the device from the

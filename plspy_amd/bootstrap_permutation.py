@@ -638,13 +638,14 @@ class _ResampleTestPLS(ResampleTest):
         def on_batch(a, z, zt, nsq):
             # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
             # (no transposes, and no division by the column norms: see lvcorr_from_latents)
-            Lt = np.take_along_axis(zt, mine[a:z][:, None, :].astype(np.int64), axis=2)
-            LVc[a:z] = cf.lvcorr_from_latents(Lt, yz(a, z), bounds)
+            # -- the engine computes exactly those columns (latent_index: the sample's rows)
+            LVc[a:z] = cf.lvcorr_from_latents(zt, yz(a, z), bounds)
             yz_of.pop((a, z), None)
             spread.add(LVc[a:z])
 
         res = eng.boot_items(mine, bounds, np.ones(len(bounds) - 1), k, ops_fn, ref=ref, on_batch=on_batch,
-                             beh=(yz, U), after_enqueue=self._finalize_early(niter, ref), need_nsq=False)
+                             beh=(yz, U), after_enqueue=self._finalize_early(niter, ref), need_nsq=False,
+                             latent_index=mine)
         std_errs, boot_ratios, (LVcorr,) = self._finish_items(res, [LVc], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = (spread.std() if nranks == 1 else np.std(LVcorr, axis=0)) * z    # :723-724

@@ -125,8 +125,9 @@ struct BehArgs {
   double cnt[AG_MAXZC], rcnt[AG_MAXZC];
   const double *a1, *mfrag, *u2;
   double *S1, *S2;                     // [split][p][k] plain partial sums (overwritten), or null
-  double *vst;                         // [items][k][ldv] or null
+  double *vst;                         // [items][k][ldv], tiled: [items][ldv / 32][k][32]; or null
   int64_t ldv;
+  int32_t vst_tiled;                   // tile-major VS^T (K5i's operand layout; ldv a multiple of 32)
 #ifdef BEH_TIMING
   long long *dbg;                      // developer-only: [workgroup][wave][8] cycle counts
 #endif
@@ -303,8 +304,14 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
 
   const bool odd = col & 1;
   const int jl = g + 8 * (int)odd;
-  const uint32_t loff = (uint32_t)(((int64_t)jl * A.ldv + (v - odd)) * 8);
+  // row-major: row j of the item at j * ldv; tile-major: the 32-voxel tile's k rows of 256 bytes side by side (a
+  // workgroup's 64 voxels are then two contiguous blocks of k x 256 bytes per item instead of k pieces of 512)
+  const int64_t rstride = A.vst_tiled ? 256 : A.ldv * 8;
+  const uint32_t loff = (uint32_t)(jl * rstride + (A.vst_tiled ? ((v - odd) >> 5) * A.k * 256 + ((v - odd) & 31) * 8
+                                                                 : (v - odd) * 8));
   const int vcode = (v - odd) + 1 < A.p ? 2 : ((v - odd) < A.p ? 1 : 0);
+  // (wave-uniform) every lane stores a pair of voxels of a row that exists: the stores need no per-lane guards
+  const bool whole = __builtin_amdgcn_ballot_w64(vcode != 2) == 0 && A.k == 16 * MC;
 
   int par = 0;
 #ifdef BEH_TIMING
@@ -412,7 +419,11 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
     for (int ii = 0; ii < IP; ++ii) {
       const int item = item0 + ii;
       if (item < it_hi) {
+#if defined(PLSR_ABLATE) && (PLSR_ABLATE & 131072)
+        const char *base = (const char *)A.vst + (int64_t)(item & 1) * A.k * A.ldv * 8;   // timing only: two items' worth of lines
+#else
         const char *base = (const char *)A.vst + (int64_t)item * A.k * A.ldv * 8;
+#endif
 #pragma unroll
         for (int mc = 0; mc < MCM; ++mc) {
           if (mc < MC) {
@@ -427,13 +438,19 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
             if (A.vst != nullptr) {
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
-                const double got = swap_pair_f64(odd ? acc2[ii][mc][h] : acc2[ii][mc][2 + h]);
-                const d2 pc = odd ? (d2){got, acc2[ii][mc][2 + h]} : (d2){acc2[ii][mc][h], got};
+                // (opaque copies: the compiler turned `odd ? acc[h] : acc[2 + h]` into an extraction at a per-lane
+                // index, a chain of three selects per register half where one does)
+                double lo_ = acc2[ii][mc][h], hi_ = acc2[ii][mc][2 + h];
+                asm volatile("" : "+v"(lo_), "+v"(hi_));
+                const double got = swap_pair_f64(odd ? lo_ : hi_);
+                const d2 pc = odd ? (d2){got, hi_} : (d2){lo_, got};
                 const int jrow = 16 * mc + 4 * h;
-                if (jl + jrow < A.k) {
-                  char *dst = (char *)base + (int64_t)jrow * A.ldv * 8 + loff;
+                char *dst = (char *)base + jrow * rstride + loff;
+                if (whole) {
+                  __builtin_nontemporal_store(pc, (d2 *)dst);          // streamed: K5 reads it back from HBM anyway
+                } else if (jl + jrow < A.k) {
                   if (vcode == 2) {
-                    __builtin_nontemporal_store(pc, (d2 *)dst);        // streamed: K5 reads it back from HBM anyway
+                    __builtin_nontemporal_store(pc, (d2 *)dst);
                   } else if (vcode == 1) {
                     *(double *)dst = pc.x;
                   }

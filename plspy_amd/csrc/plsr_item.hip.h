@@ -250,6 +250,75 @@ struct LatentXtArgs {
   double *nsq_part;       // [nchunk][items][k] or null
 };
 
+// Rows of X an item's sample holds: rows[item][0 .. nu) ascending (padded with the last one), cols[item][i] =
+// position of idx[item][i] in that list.  A sample with a row outside [0, n) or with more than max_rows
+// different rows gets nu = -1 (latent_index_sum_kernel then fills the item with NaN).  One workgroup of
+// XT_LD threads per item.
+__global__ __launch_bounds__(128) void latent_index_meta_kernel(const int32_t *idx, int m, int n, int max_rows,
+                                                                int32_t *rows, int32_t *nu, int32_t *cols) {
+  __shared__ int flag[128];
+  __shared__ int rank[128];
+  __shared__ int bad, half;
+  const int item = blockIdx.x, t = threadIdx.x;
+  flag[t] = 0;
+  if (t == 0) bad = 0;
+  __syncthreads();
+  const int32_t *ix = idx + (int64_t)item * m;
+  for (int i = t; i < m; i += 128) {
+    const int r = ix[i];
+    if (r < 0 || r >= n) bad = 1;
+    else flag[r] = 1;
+  }
+  __syncthreads();
+  const unsigned long long mask = __ballot(flag[t] != 0);
+  if (t == 0) half = __popcll(mask);
+  __syncthreads();
+  const int below = __popcll(mask & ((1ull << (t & 63)) - 1ull)) + (t >= 64 ? half : 0);
+  rank[t] = below;
+  __shared__ int total;
+  if (t == 127) total = below + (flag[t] ? 1 : 0);
+  __syncthreads();
+  const int cnt = total;
+  int32_t *ro = rows + (int64_t)item * 128;
+  if (flag[t]) ro[below] = t;
+  __syncthreads();
+  if (!bad && cnt > 0 && cnt <= max_rows) {
+    const int last = ro[cnt - 1];
+    if (t >= cnt) ro[t] = last;
+    for (int i = t; i < m; i += 128) cols[(int64_t)item * m + i] = rank[ix[i]];
+    if (t == 0) nu[item] = cnt;
+  } else {
+    ro[t] = 0;
+    for (int i = t; i < m; i += 128) cols[(int64_t)item * m + i] = 0;
+    if (t == 0) nu[item] = -1;
+  }
+}
+
+// L[item][j][i] = sum over chunks of part[chunk][item][j][cols[item][i]]   (NaN for a refused item)
+__global__ __launch_bounds__(256) void latent_index_sum_kernel(const double *part, int64_t items, int k, int nr,
+                                                               int nchunk, const int32_t *cols, const int32_t *nu,
+                                                               int m, double *L) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= items * k * m) return;
+  const int i = (int)(e % m);
+  const int64_t bj = e / m;
+  const int64_t item = bj / k;
+  if (nu[item] < 0) {
+    L[e] = __builtin_nan("");
+    return;
+  }
+  const int64_t E = items * k * nr;
+  const double *src = part + bj * nr + cols[item * m + i];
+  double a0 = 0.0, a1 = 0.0;
+  int c = 0;
+  for (; c + 1 < nchunk; c += 2) {
+    a0 += src[(int64_t)c * E];
+    a1 += src[(int64_t)(c + 1) * E];
+  }
+  if (c < nchunk) a0 += src[(int64_t)c * E];
+  L[e] = a0 + a1;
+}
+
 template <int MC, int WV>
 __global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -398,6 +467,244 @@ __global__ __launch_bounds__(WV * 64, 2) void latent_xt_kernel(LatentXtArgs A) {
       for (int w = 0; w < WV; ++w) x += red[w * (MC * 16) + tid];
       A.nsq_part[((int64_t)chunk * A.items + item) * A.k + tid] = x;
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// K5i: the latent scores of a SAMPLE, L_b = (X[idx_b] VS_b^T)^T, on the different rows of the sample only.
+//
+// A bootstrap sample of n rows holds about 0.63 n different rows, and `_compute_X_latents(X_new, V_hat)` needs no
+// others (76 of 120 at config 3: five 16-row tiles instead of eight).  One WAVE = (item, range of voxels): it holds
+// the accumulators of ALL the item's live row tiles x ALL tiles of latent variables (NT x MC x 4 registers) and
+// streams both operands straight from global memory, each byte read once by one wave -- no LDS, no barrier:
+//   * B: lane (row, g) reads voxels 16 j + 4 g .. + 3 of entry `row` of the item's sorted row list
+//     (latent_index_meta_kernel) from a TILE-MAJOR copy of X, XB[tile of 32 voxels][row][32] (voxels past p zero;
+//     xb_prepare_kernel, once per X): one 32-byte load per lane = one whole 128-byte line per row and instruction,
+//     the row choice is the lane's own offset -- no gather;
+//   * A: lane (latent variable, g) reads the same four voxels of its row of VS^T; k-step e of the group multiplies
+//     voxel 16 j + 4 g + e on both sides.
+// A group = MC + NT loads of 32 bytes per lane, 4 NT MC MFMAs.  The VS^T operands (from HBM) sit in two register sets
+// used in turn, two groups of prefetch; a row tile's B registers (XB: from L2) are refilled right after its MFMAs.  The item's number of live tiles is a wave-uniform switch
+// over instances of the loop (NT = 1 .. 8).  Workgroup id -> (item, range) keeps the ranges of an XCD apart from the
+// other XCDs' (id mod 8 = range mod 8) and its resident waves on the same ranges of different items: XB streams
+// through that XCD's L2 once per batch of items.
+//
+// What came before (config 3, us per item; K5x on all 128 rows: 39-42): K5x's workgroup (one wave per row tile, VS^T
+// through LDS) on the row lists -- through X^T 43, through X itself 54, through XB 42, with two tiles of prefetch
+// 40.  Ablation builds (`microbench/latent_index_once.py`): without the MFMAs 27, and without any one of B loads /
+// VS^T loads / LDS reads still 43 -- the six waves of a workgroup (five live) sit 2-2-1-1 on the four SIMDs, the
+// second workgroup of the CU the same way, so one SIMD carries four live waves where 2.5 would be its share.  A
+// wave per (item, voxel range) is balanced whatever the number of live tiles.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xb_prepare_kernel(const double *X, int64_t ldx, int64_t p, int n, double *XB) {
+  // one thread per pair of voxels: XB[t][r][2 q .. 2 q + 1], 16 threads per row of a tile
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nvt = (p + LV_T - 1) / LV_T;
+  if (e >= nvt * n * 16) return;
+  const int q = (int)(e & 15);
+  const int64_t tr = e >> 4;
+  const int r = (int)(tr % n);
+  const int64_t v = (tr / n) * LV_T + 2 * q;
+  const double *src = X + (int64_t)r * ldx;
+  XB[2 * e] = v < p ? src[v] : 0.0;
+  XB[2 * e + 1] = v + 1 < p ? src[v + 1] : 0.0;
+}
+
+struct LatentWaveArgs {
+  const double *XB;       // [tiles][n][32]
+  int64_t p;
+  int32_t n, k, items;
+  const double *vst;      // [items][k][ldv]; tiled: [items][ldv / 32][k][32]
+  int64_t ldv;
+  int32_t vst_tiled;
+  int32_t nsplit;         // voxel ranges per item (a multiple of 8)
+  int32_t tiles_per_split;
+  double *Zt_part;        // [nsplit][items][k][nr]
+  double *nsq_part;       // [nsplit][items][k] or null
+  const int32_t *rows;    // [items][XT_LD]
+  const int32_t *nu;      // [items]
+  int32_t nr;             // columns of Zt_part (a multiple of 16)
+  int32_t tile_lo;        // first row tile of this launch (see latent_wave_kernel)
+};
+
+template <int MC, int NT>
+__device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int item, int split, int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int col = lane & 15;
+  const int g = lane >> 4;
+  const int64_t nvt = (A.p + LV_T - 1) / LV_T;
+  const int64_t t_lo = (int64_t)split * A.tiles_per_split;
+  const int64_t t_hi = min(nvt, t_lo + A.tiles_per_split);
+
+  f64x4 acc[NT][MC];
+  double nsq[MC];
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc) {
+    nsq[mc] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i][mc] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  }
+  // 32-bit byte offsets of this lane's rows from the (scalar) start of a tile (the library checks the sizes)
+  uint32_t offa[MC], offb[NT];
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc) offa[mc] = (uint32_t)(((int64_t)min(mc * 16 + col, A.k - 1) * (A.vst_tiled ? LV_T : A.ldv) + 2 * g) * 8);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int r = min(max(A.rows[(int64_t)item * XT_LD + 16 * (A.tile_lo + i) + col], 0), A.n - 1);
+    offb[i] = (uint32_t)((r * LV_T + 2 * g) * 8);
+  }
+  // Both operands through buffer descriptors based at the range's first tile: a load is descriptor + this lane's 32-bit
+  // row offset + a scalar tile offset (+ immediate), no 64-bit address arithmetic in registers (with plain pointers
+  // the compiler kept a 64-bit address pair per row tile and doubled the B registers: 250 VGPRs and scratch for what
+  // needs 110).
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const char *vbase = (const char *)(A.vst + (int64_t)item * A.k * A.ldv);
+  const int64_t xts = (int64_t)A.n * LV_T * 8;                    // bytes per tile of XB
+  // bytes from one tile of VS^T to the next: row-major 256 (a row's next 32 voxels), tile-major the tile's k rows
+  const int64_t vts = A.vst_tiled ? (int64_t)A.k * LV_T * 8 : LV_T * 8;
+  const int64_t vrange = (int64_t)A.k * A.ldv * 8 - t_lo * vts;
+  const int64_t xrange = (nvt - t_lo) * xts;
+  const auto vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(vbase + t_lo * vts), 0,
+                                                      (int)min(vrange, (int64_t)0x7fffffff), 0x00020000);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)A.XB + t_lo * xts), 0,
+                                                      (int)min(xrange, (int64_t)0x7fffffff), 0x00020000);
+  auto load16 = [&](decltype(vsrc) src, uint32_t voff, uint32_t soff) -> d2 {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(src, voff, soff, 0);
+    union {
+      u32x4 u;
+      d2 d;
+    } cv;
+    cv.u = u;
+    return cv.d;
+  };
+
+  // group (tile t, j = 0 .. 3): voxels 8 j .. 8 j + 7 of the tile, two k-steps: lane (row, g) holds voxels 8 j + 2 g + {0, 1}
+  // of its row (16 bytes; the four lanes of a row read 64 contiguous bytes).  The loop runs over the WHOLE tiles of the
+  // range (its prefetches stop at the last of them); the tile that holds voxels past p, if the range ends with it,
+  // follows with element-wise clamped loads of VS^T (its voxels past p are zero in XB).
+  const int64_t t_full = min(t_hi, A.p / LV_T);
+  auto mfmas = [&](const d2 (&a)[MC], const d2 &b, int i) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) acc[i][mc] = mfma_f64(a[mc][e], b[e], acc[i][mc]);
+  };
+  if (t_lo < t_full) {
+    // Two groups per loop iteration, the two A sets (group in use / two groups on) with static names.
+    d2 a0[MC], a1[MC], b[NT];
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) a0[mc] = load16(vsrc, offa[mc], 0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) b[i] = load16(xsrc, offb[i], 0);
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) a1[mc] = load16(vsrc, offa[mc], 64);
+    const int nq = 4 * (int)(t_full - t_lo);                     // (even)
+    const uint32_t xts32 = (uint32_t)xts, vts32 = (uint32_t)vts;
+    // one group: MFMAs row tile by row tile, the tile's B registers refilled (next group: XB comes from L2) right behind
+    // them; the column norms of VS^T and the prefetch of group q + 2's A operands (VS^T comes from HBM) at the end; the
+    // last groups' prefetches re-read the last group
+    auto group = [&](int q, d2 (&a)[MC]) {
+      const int q1 = min(q + 1, nq - 1), q2 = min(q + 2, nq - 1);
+      const uint32_t xnext = (uint32_t)(q1 >> 2) * xts32 + (uint32_t)(q1 & 3) * 64;
+      const uint32_t vnext = (uint32_t)(q2 >> 2) * vts32 + (uint32_t)(q2 & 3) * 64;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        mfmas(a, b[i], i);
+        b[i] = load16(xsrc, offb[i], xnext);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) {
+        nsq[mc] = fma(a[mc][0], a[mc][0], nsq[mc]);
+        nsq[mc] = fma(a[mc][1], a[mc][1], nsq[mc]);
+        a[mc] = load16(vsrc, offa[mc], vnext);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // the prologue's loads are drained here: with them pending, the wait-count pass merges their state into the loop
+    // header and every iteration starts with vmcnt(1), i.e. behind the A loads it has just issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma nounroll
+    for (int q = 0; q < nq; q += 2) {
+      group(q, a0);
+      group(q + 1, a1);
+    }
+  }
+  if (t_lo < t_hi && t_full < t_hi) {
+    const int64_t t = t_full;                                     // == nvt - 1, p % 32 != 0
+    for (int j = 0; j < 4; ++j) {
+      d2 a[MC];
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) {
+        // (row-major: the row's voxel v at 8 v; tile-major: this tile's row at t vts, voxel v mod 32)
+        const char *rowp = vbase + offa[mc] - 2 * g * 8 + (A.vst_tiled ? t * vts - t * (LV_T * 8) : 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int64_t v = t * LV_T + 8 * j + 2 * g + e;
+          const double x = *(const double *)(rowp + min(v, A.p - 1) * 8);
+          a[mc][e] = v < A.p ? x : 0.0;
+          nsq[mc] = fma(a[mc][e], a[mc][e], nsq[mc]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const d2 b = *(const d2 *)((const char *)A.XB + t * xts + offb[i] + j * 64);
+        mfmas(a, b, i);
+      }
+    }
+  }
+
+  // Zt[j = 16 mc + g + 4 r][i' = 16 i + col]
+  double *zo = A.Zt_part + ((int64_t)split * A.items + item) * A.k * A.nr;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = mc * 16 + g + 4 * r;
+        if (j < A.k) zo[(int64_t)j * A.nr + 16 * (A.tile_lo + i) + col] = acc[i][mc][r];
+      }
+  if (A.nsq_part) {
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
+      double x = nsq[mc];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      const int j = mc * 16 + col;
+      if (g == 0 && j < A.k) A.nsq_part[((int64_t)split * A.items + item) * A.k + j] = x;
+    }
+  }
+}
+
+// A wave holds at most latent_wave_cap(MC) row tiles (NT x MC x 8 accumulator registers of the 256 at two waves per
+// SIMD).  Items with more live tiles (a wide sample; k > 48) get the rest from a second launch with tile_lo = cap,
+// whose waves for all other items leave at once.
+constexpr int latent_wave_cap(int mc) { return 18 / mc > 8 ? 8 : 18 / mc; }
+
+template <int MC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void latent_wave_kernel(LatentWaveArgs A) {
+  constexpr int CAP = latent_wave_cap(MC);
+  const int lane = threadIdx.x;
+  // id mod 8 (the XCD) = split mod 8; consecutive ids of an XCD: the items of one split
+  const int64_t id = blockIdx.x;
+  const int x = (int)(id & 7);
+  const int64_t q = id >> 3;
+  const int item = (int)(q % A.items);
+  const int split = (int)(q / A.items) * 8 + x;
+  const int nu = A.nu[item];
+  const int nt = __builtin_amdgcn_readfirstlane(nu < 0 ? 0 : min(((nu + 15) >> 4) - A.tile_lo, CAP));
+  switch (nt) {
+    case 1: latent_wave_body<MC, 1>(A, item, split, lane); break;
+    case 2: latent_wave_body<MC, 2>(A, item, split, lane); break;
+    case 3: latent_wave_body<MC, 3>(A, item, split, lane); break;
+    case 4: latent_wave_body<MC, 4>(A, item, split, lane); break;
+    case 5: if constexpr (CAP >= 5) latent_wave_body<MC, 5>(A, item, split, lane); break;
+    case 6: if constexpr (CAP >= 6) latent_wave_body<MC, 6>(A, item, split, lane); break;
+    case 7: if constexpr (CAP >= 7) latent_wave_body<MC, 7>(A, item, split, lane); break;
+    case 8: if constexpr (CAP >= 8) latent_wave_body<MC, 8>(A, item, split, lane); break;
+    default: break;                                  // (nothing for this launch, or a refused item: NaN from the sum kernel)
   }
 }
 

@@ -196,6 +196,64 @@ extern "C" int plsr_latent_xt_prepare(const double *d_X, int64_t ldx, int64_t p,
   return launch_ok();
 }
 
+namespace {
+// chunks of voxel tiles for a launch of `items` workgroups that fit `slots` at a time: the last round of resident
+// workgroups as full as the others
+void latent_xt_chunks(int32_t items, int64_t p, int slots, int32_t k, int32_t ncol, LatentPlan &pl) {
+  const int64_t nvt = (p + LV_T - 1) / LV_T;
+  const int lo = (int)std::max<int64_t>(1, (768 + items - 1) / items);
+  const int hi = (int)std::max<int64_t>(lo, (2048 + items - 1) / items);
+  int want = lo;
+  double best = -1.0;
+  for (int c = lo; c <= hi; ++c) {
+    const double rounds = (double)items * c / (double)slots;
+    const double eff = rounds / std::ceil(rounds);
+    if (eff > best + 1e-3) {
+      best = eff;
+      want = c;
+    }
+  }
+  want = (int)std::min<int64_t>(want, nvt);
+  pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
+  pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
+  pl.z_elems = (size_t)pl.nchunk * items * k * ncol;
+  pl.n_elems = (size_t)pl.nchunk * items * k;
+  pl.bytes = ((pl.z_elems + pl.n_elems) * sizeof(double) + 511) / 256 * 256;
+}
+
+int latent_xt_launch(const LatentXtArgs &a, int MC, int WV, int nchunk, hipStream_t st) {
+  const size_t lds = std::max((size_t)2 * MC * 16 * XT_VLD, (size_t)8 * MC * 16) * sizeof(double);
+  int rc = PLSR_EUNSUPPORTED;
+#define PLSR_LX(M, W)                                                                                              \
+  if (MC == M && WV <= W && rc == PLSR_EUNSUPPORTED) {                                                             \
+    hipLaunchKernelGGL((latent_xt_kernel<M, W>), dim3((unsigned)a.items, (unsigned)nchunk), dim3(W * 64), lds, st, \
+                       a);                                                                                         \
+    rc = launch_ok();                                                                                              \
+  }
+  PLSR_LX(1, 4) PLSR_LX(1, 8) PLSR_LX(2, 4) PLSR_LX(2, 8) PLSR_LX(3, 4) PLSR_LX(3, 8) PLSR_LX(4, 4) PLSR_LX(4, 8)
+#undef PLSR_LX
+  return rc;
+}
+
+// K5i: columns of the partial outputs, voxel ranges per item, workspace
+inline int index_cols(int32_t max_rows) { return (max_rows + 15) / 16 * 16; }
+inline size_t index_meta_bytes(int32_t items, int32_t m) {
+  return (((size_t)items * (XT_LD + 1 + m)) * sizeof(int32_t) + 255) / 256 * 256;
+}
+// about four rounds of the chip's 2048 wave slots (two waves per SIMD), a multiple of 8, at least 16 tiles each
+inline void index_splits(int32_t items, int64_t p, int &nsplit, int &tiles_per_split) {
+  const int64_t nvt = (p + LV_T - 1) / LV_T;
+  int64_t s = (8192 + (int64_t)items * 8 - 1) / ((int64_t)items * 8) * 8;
+  s = std::min<int64_t>(s, std::max<int64_t>(8, nvt / 16 / 8 * 8));
+  s = std::max<int64_t>(8, std::min<int64_t>(s, 512));
+  tiles_per_split = (int)((nvt + s - 1) / s);
+  nsplit = (int)s;
+}
+inline size_t index_part_bytes(int32_t items, int32_t k, int ncol, int nsplit) {
+  return (((size_t)nsplit * items * k * (ncol + 1)) * sizeof(double) + 511) / 256 * 256;
+}
+}  // namespace
+
 extern "C" int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const double *d_vst, int64_t ldv,
                               int32_t items, int32_t k, double *d_Zt, double *d_nsq, void *d_work, size_t work_bytes,
                               void *stream) {
@@ -203,28 +261,7 @@ extern "C" int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const do
   if (n <= 0 || n > XT_LD || k <= 0 || k > 64) return PLSR_EUNSUPPORTED;
   LatentPlan pl;
   if (!latent_plan(n, k, items, p, pl)) return PLSR_EUNSUPPORTED;
-  // one item per workgroup here: chunks for `items` groups
-  {
-    const int64_t nvt = (p + LV_T - 1) / LV_T;
-    const int lo = (int)std::max<int64_t>(1, (768 + items - 1) / items);
-    const int hi = (int)std::max<int64_t>(lo, (2048 + items - 1) / items);
-    int want = lo;
-    double best = -1.0;
-    for (int c = lo; c <= hi; ++c) {
-      const double rounds = (double)items * c / 512.0;
-      const double eff = rounds / std::ceil(rounds);
-      if (eff > best + 1e-3) {
-        best = eff;
-        want = c;
-      }
-    }
-    want = (int)std::min<int64_t>(want, nvt);
-    pl.tiles_per_chunk = (int)((nvt + want - 1) / want);
-    pl.nchunk = (int)((nvt + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk);
-    pl.z_elems = (size_t)pl.nchunk * items * k * n;
-    pl.n_elems = (size_t)pl.nchunk * items * k;
-    pl.bytes = ((pl.z_elems + pl.n_elems) * sizeof(double) + 511) / 256 * 256;
-  }
+  latent_xt_chunks(items, p, 512, k, n, pl);        // one item per workgroup here: chunks for `items` groups
   if (pl.bytes > work_bytes) return PLSR_EWORKSPACE;
   if ((int64_t)k * ldv * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;
   LatentXtArgs a;
@@ -239,17 +276,7 @@ extern "C" int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const do
   a.Zt_part = (double *)d_work;
   a.nsq_part = d_nsq ? a.Zt_part + pl.z_elems : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int MC = (k + 15) / 16, WV = (n + 15) / 16;
-  const size_t lds = std::max((size_t)2 * MC * 16 * XT_VLD, (size_t)8 * MC * 16) * sizeof(double);
-  int rc = PLSR_EUNSUPPORTED;
-#define PLSR_LX(M, W)                                                                                              \
-  if (MC == M && WV <= W && rc == PLSR_EUNSUPPORTED) {                                                             \
-    hipLaunchKernelGGL((latent_xt_kernel<M, W>), dim3((unsigned)items, (unsigned)pl.nchunk), dim3(W * 64), lds, st, \
-                       a);                                                                                         \
-    rc = launch_ok();                                                                                              \
-  }
-  PLSR_LX(1, 4) PLSR_LX(1, 8) PLSR_LX(2, 4) PLSR_LX(2, 8) PLSR_LX(3, 4) PLSR_LX(3, 8) PLSR_LX(4, 4) PLSR_LX(4, 8)
-#undef PLSR_LX
+  const int rc = latent_xt_launch(a, (k + 15) / 16, (n + 15) / 16, pl.nchunk, st);
   if (rc) return rc;
   const int64_t EZ = (int64_t)items * k * n, EN = (int64_t)items * k;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EZ + 255) / 256), 1), dim3(256), 0, st,
@@ -265,6 +292,93 @@ extern "C" size_t plsr_latent_xt_workspace_bytes(int32_t n, int32_t k, int32_t i
   const int64_t nvt = (p + LV_T - 1) / LV_T;
   const int64_t hi = std::min<int64_t>(nvt, std::max<int64_t>(1, (2048 + items - 1) / items));
   return (size_t)(((size_t)hi * items * k * (n + 1)) * sizeof(double) + 511) / 256 * 256;
+}
+
+// K5i: L_b = (X[idx_b] VS_b^T)^T from the rows of X the sample holds, each once
+extern "C" size_t plsr_latent_xb_bytes(int32_t n, int64_t p) {
+  if (n <= 0 || n > XT_LD || p <= 0) return 0;
+  return (size_t)((p + LV_T - 1) / LV_T * LV_T) * n * sizeof(double);
+}
+
+extern "C" int plsr_latent_xb_prepare(const double *d_X, int64_t ldx, int64_t p, int32_t n, double *d_XB, void *stream) {
+  if (!d_X || !d_XB || n <= 0 || n > XT_LD || p <= 0 || ldx < p) return PLSR_EINVAL;
+  const int64_t E = (p + LV_T - 1) / LV_T * n * 16;
+  hipLaunchKernelGGL(xb_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_X, ldx, p,
+                     n, d_XB);
+  return launch_ok();
+}
+
+extern "C" size_t plsr_latent_index_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p, int32_t m,
+                                                    int32_t max_rows) {
+  if (n <= 0 || n > XT_LD || k <= 0 || k > 64 || items <= 0 || p <= 0 || m <= 0 || max_rows <= 0 || max_rows > n)
+    return 0;                                        // (the row lists hold up to XT_LD = 128 rows of X)
+  if ((int64_t)items * k * m >= ((int64_t)1 << 31)) return 0;
+  if ((int64_t)k * ((p + LV_T - 1) / LV_T * LV_T) * 8 >= ((int64_t)1 << 32)) return 0;   // 32-bit offsets into an item's VS^T
+  int nsplit, tps;
+  index_splits(items, p, nsplit, tps);
+  return index_meta_bytes(items, m) + index_part_bytes(items, k, index_cols(max_rows), nsplit);
+}
+
+extern "C" int plsr_latent_index(const double *d_XB, int64_t p, int32_t n, const double *d_vst, int64_t ldv,
+                                 int32_t vst_tiled, int32_t items, int32_t k, const int32_t *d_idx, int32_t m,
+                                 int32_t max_rows, double *d_L, double *d_nsq, void *d_work, size_t work_bytes,
+                                 void *stream) {
+  if (!d_XB || !d_vst || !d_L || !d_work || !d_idx || ldv < p) return PLSR_EINVAL;
+  if (vst_tiled && ldv % LV_T != 0) return PLSR_EINVAL;
+  const size_t need = plsr_latent_index_workspace_bytes(n, k, items, p, m, max_rows);
+  if (!need) return PLSR_EUNSUPPORTED;
+  if (need > work_bytes) return PLSR_EWORKSPACE;
+  if ((int64_t)k * ldv * 8 >= ((int64_t)1 << 32) || (int64_t)n * LV_T * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;
+  LatentWaveArgs a;
+  index_splits(items, p, a.nsplit, a.tiles_per_split);
+  if ((int64_t)items * a.nsplit >= ((int64_t)1 << 31)) return PLSR_EUNSUPPORTED;
+  const size_t meta = index_meta_bytes(items, m);
+  int32_t *rows = (int32_t *)d_work;
+  int32_t *nu = rows + (size_t)items * XT_LD;
+  int32_t *cols = nu + items;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(latent_index_meta_kernel, dim3((unsigned)items), dim3(128), 0, st, d_idx, (int)m, (int)n,
+                     (int)max_rows, rows, nu, cols);
+  a.XB = d_XB;
+  a.p = p;
+  a.n = n;
+  a.k = k;
+  a.items = items;
+  a.vst = d_vst;
+  a.ldv = ldv;
+  a.vst_tiled = vst_tiled != 0;
+  a.nr = index_cols(max_rows);
+  a.Zt_part = (double *)((char *)d_work + meta);
+  a.nsq_part = d_nsq ? a.Zt_part + (size_t)a.nsplit * items * k * a.nr : nullptr;
+  a.rows = rows;
+  a.nu = nu;
+  const int MC = (k + 15) / 16;
+  const unsigned grid = (unsigned)((int64_t)items * a.nsplit);
+  int rc = PLSR_EUNSUPPORTED;
+#define PLSR_LW(M)                                                                            \
+  if (MC == M) {                                                                              \
+    a.tile_lo = 0;                                                                            \
+    hipLaunchKernelGGL((latent_wave_kernel<M>), dim3(grid), dim3(64), 0, st, a);              \
+    if (a.nr / 16 > latent_wave_cap(M)) { /* the row tiles past a wave's capacity */          \
+      a.tile_lo = latent_wave_cap(M);                                                         \
+      a.nsq_part = nullptr;                                                                   \
+      hipLaunchKernelGGL((latent_wave_kernel<M>), dim3(grid), dim3(64), 0, st, a);            \
+    }                                                                                         \
+    rc = launch_ok();                                                                         \
+  }
+  double *const nsq_part = a.nsq_part;
+  PLSR_LW(1) PLSR_LW(2) PLSR_LW(3) PLSR_LW(4)
+  a.nsq_part = nsq_part;
+#undef PLSR_LW
+  if (rc) return rc;
+  const int64_t EL = (int64_t)items * k * m, EN = (int64_t)items * k;
+  hipLaunchKernelGGL(latent_index_sum_kernel, dim3((unsigned)((EL + 255) / 256)), dim3(256), 0, st,
+                     (const double *)a.Zt_part, (int64_t)items, (int)k, (int)a.nr, (int)a.nsplit,
+                     (const int32_t *)cols, (const int32_t *)nu, (int)m, d_L);
+  if (d_nsq)
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
+                       (const double *)a.nsq_part, d_nsq, EN, a.nsplit, a.nsplit);
+  return launch_ok();
 }
 
 // ---------------------------------------------------------------------------
@@ -1030,9 +1144,10 @@ extern "C" int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t 
                              const int32_t *cell_lo, const int32_t *src_lo, const int32_t *src_hi, int32_t ncell,
                              const double *d_Yz, int32_t b, const double *d_U, int32_t items, int32_t k,
                              const double *d_ref, double *d_S1, double *d_S2, double *d_vst, int64_t ldv,
-                             void *d_work, size_t work_bytes, void *stream) {
+                             int32_t vst_tiled, void *d_work, size_t work_bytes, void *stream) {
   if (!d_X || !d_src || !d_Yz || !d_U || !d_work || !cell_lo || !src_lo || !src_hi || ldx < p) return PLSR_EINVAL;
   if ((d_S1 == nullptr) != (d_S2 == nullptr) || (d_vst && ldv < p)) return PLSR_EINVAL;
+  if (d_vst && vst_tiled && ldv % LV_T != 0) return PLSR_EINVAL;
   if (d_vst && (12 * ldv + p) * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;   // 32-bit lane offsets of the stores
   BehPlan pl;
   if (!beh_plan(n, nz, b, k, cell_lo, src_lo, src_hi, ncell, items, p, d_S1 != nullptr, pl)) return PLSR_EUNSUPPORTED;
@@ -1092,6 +1207,7 @@ extern "C" int plsr_item_beh(const double *d_X, int64_t ldx, int64_t p, int32_t 
   a.S2 = d_S1 ? a.S1 + (size_t)pl.nsplit * p * k : nullptr;
   a.vst = d_vst;
   a.ldv = ldv;
+  a.vst_tiled = vst_tiled != 0;
 #ifdef BEH_TIMING
   static long long *bdbg = nullptr;
   const size_t nbdbg = (size_t)pl.nwg * pl.nsplit * BH_WAVES * 8;

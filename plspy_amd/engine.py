@@ -155,6 +155,8 @@ class ProjectionEngine:
         self._pool = {}
         self._XT = None
         self._XT_n = 0
+        self._XB = None
+        self._XB_n = 0
         self._tail = None
         self._h2d = None
         self._d2h = None
@@ -180,6 +182,8 @@ class ProjectionEngine:
         self._lanes.clear()
         self._XT = None
         self._XT_n = 0
+        self._XB = None
+        self._XB_n = 0
 
     def dev(self, a, dtype=torch.float64):
         """Device copy of a host array (or the tensor itself if it is already
@@ -442,15 +446,9 @@ class ProjectionEngine:
         fragments (made once per engine); otherwise through the LDS-staged kernel."""
         cnt, k = int(vst.shape[0]), int(vst.shape[1])
         if n <= 128 and k <= 64 and os.environ.get("PLSR_LATENT_XT", "1") != "0":
-            if self._XT is None or self._XT_n != n:
-                nb = self.lib.plsr_latent_xt_bytes(n, self.p)
-                self._XT = torch.empty(nb // 8, dtype=torch.float64, device=self.device)
-                _lib.check(self.lib.plsr_latent_xt_prepare(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(self._XT),
-                                                           _stream()), "plsr_latent_xt_prepare")
-                self._XT_n = n
             need = self.lib.plsr_latent_xt_workspace_bytes(n, k, cnt, self.p)
             work = self._buf("k5work", need)
-            _lib.check(self.lib.plsr_latent_xt(_ptr(self._XT), self.p, n, _ptr(vst), vst.stride(1), cnt, k, _ptr(Zt),
+            _lib.check(self.lib.plsr_latent_xt(_ptr(self._xt(n)), self.p, n, _ptr(vst), vst.stride(1), cnt, k, _ptr(Zt),
                                                _ptr(nsq), _ptr(work), need, _stream()), "plsr_latent_xt")
             return
         need = self.lib.plsr_latent_workspace_bytes(n, k, cnt, self.p)
@@ -459,6 +457,60 @@ class ProjectionEngine:
         work = self._buf("k5work", need)
         _lib.check(self.lib.plsr_latent(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(vst), vst.stride(1), cnt, k,
                                         _ptr(Zt), _ptr(nsq), _ptr(work), need, _stream()), "plsr_latent")
+
+    def _xt(self, n):
+        if self._XT is None or self._XT_n != n:
+            nb = self.lib.plsr_latent_xt_bytes(n, self.p)
+            self._XT = torch.empty(nb // 8, dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.plsr_latent_xt_prepare(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(self._XT),
+                                                       _stream()), "plsr_latent_xt_prepare")
+            self._XT_n = n
+        return self._XT
+
+    def _xb(self, n):
+        """Tile-major copy of X[:n] (K5i's operand), made once per engine."""
+        if self._XB is None or self._XB_n != n:
+            nb = self.lib.plsr_latent_xb_bytes(n, self.p)
+            self._XB = torch.empty(nb // 8, dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.plsr_latent_xb_prepare(_ptr(self.X), self.X.stride(0), self.p, n, _ptr(self._XB),
+                                                       _stream()), "plsr_latent_xb_prepare")
+            self._XB_n = n
+        return self._XB
+
+    @staticmethod
+    def distinct_rows(idx):
+        """Largest number of different entries in a row of idx (cnt, m)."""
+        srt = np.sort(idx, axis=1)
+        return int((np.count_nonzero(srt[:, 1:] != srt[:, :-1], axis=1) + 1).max())
+
+    def index_served(self, n, k, cnt, m, most):
+        """Whether K5i serves a batch of cnt samples of m rows with at most `most` different ones."""
+        return bool(most) and n <= 128 and self.lib.plsr_latent_index_workspace_bytes(n, k, cnt, self.p, m, most) > 0
+
+    def latent_batch_index(self, vst, n, idx, d_idx, L, nsq=None, tiled=False, most=None):
+        """K5i: L (cnt, k, m) <- (X[idx_b] VS_b^T)^T, the latent scores of every sample's own rows
+        (`_compute_X_latents(X_new, V_hat)` before the normalisation), computed on the rows of X the sample
+        holds, each once (plsr_latent_index).  idx (cnt, m): host copy of d_idx (int32, rows of X[:n]).
+        tiled: vst is tile-major (item_beh(tiled=True); only K5i reads that layout).
+        Shapes the library does not serve (n > 128): the full product and a gather of its columns."""
+        cnt, k = int(vst.shape[0]), int(vst.shape[1])
+        m = int(idx.shape[1])
+        if most is None:
+            most = self.distinct_rows(idx) if n <= 128 else 0
+        if self.index_served(n, k, cnt, m, most):
+            need = self.lib.plsr_latent_index_workspace_bytes(n, k, cnt, self.p, m, most)
+            work = self._buf("k5work", need)
+            _lib.check(self.lib.plsr_latent_index(_ptr(self._xb(n)), self.p, n, _ptr(vst), vst.stride(1), int(tiled),
+                                                  cnt, k, _ptr(d_idx), m, most, _ptr(L), _ptr(nsq), _ptr(work),
+                                                  need, _stream()), "plsr_latent_index")
+            self.last_latent_kernel = "index"
+            return
+        if tiled:
+            raise _lib.PlsrError("tile-major VS^T is only read by plsr_latent_index")
+        Zt = torch.empty((cnt, k, n), dtype=torch.float64, device=self.device)
+        self.latent_batch(vst, n, Zt, nsq)
+        torch.gather(Zt, 2, d_idx.long()[:, None, :].expand(cnt, k, m), out=L)
+        self.last_latent_kernel = "full"
 
     def latents_device(self, vt):
         """(1, k, n) device tensor (X @ V)^T for V^T = vt (k, p) on the device (K5, one item)."""
@@ -739,14 +791,17 @@ class ProjectionEngine:
             _stream()), "plsr_item_fused")
         return vst, (rowsq[:, :k] if want_rowsq else None)
 
-    def _vst(self, items, k, pool):
+    def _vst(self, items, k, pool, ld=None):
+        ld = self.p if ld is None else ld
         if not pool:
-            return torch.empty((items, k, self.p), dtype=torch.float64, device=self.device)
-        return self._buf("vst", items * k * self.p * 8)[:items * k * self.p * 8].view(torch.float64).view(items, k, self.p)
+            return torch.empty((items, k, ld), dtype=torch.float64, device=self.device)
+        return self._buf("vst", items * k * ld * 8)[:items * k * ld * 8].view(torch.float64).view(items, k, ld)
 
-    def item_beh(self, src, cell_lo, ranges, Yz, U, ref=None, S1=None, S2=None, want_vst=True, pool=False):
+    def item_beh(self, src, cell_lo, ranges, Yz, U, ref=None, S1=None, S2=None, want_vst=True, pool=False, tiled=False):
         """K4b: VS_b of behaviour PLS in two stages (plsr_item_beh), or None when the shape is not
-        served.  src (items, nz), Yz (items, nz, b) z-scored within the cells, U (ncell * b, k)."""
+        served.  src (items, nz), Yz (items, nz, b) z-scored within the cells, U (ncell * b, k).
+        tiled: VS^T leaves tile-major, (items, p_pad / 32, k, 32) in a block of (items, k, p_pad) doubles -- the
+        layout latent_batch_index streams (see plsr.h)."""
         d_src = self.dev(src, torch.int32)
         d_Yz = self.dev(Yz)
         d_U = self.dev(U)
@@ -763,11 +818,12 @@ class ProjectionEngine:
         self.last_item_kernel = "beh"
         work = self._buf("k4work", need) if pool else torch.empty(need, dtype=torch.uint8, device=self.device)
         refd = self.dev(ref)
-        vst = self._vst(items, k, pool) if want_vst else None
+        ld = (self.p + 31) // 32 * 32 if tiled else self.p
+        vst = self._vst(items, k, pool, ld) if want_vst else None
         _lib.check(self.lib.plsr_item_beh(
             _ptr(self.X), self.X.stride(0), self.p, self.n, _ptr(d_src), nz, lo, slo, shi, ncell, _ptr(d_Yz), b,
-            _ptr(d_U), items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), self.p, _ptr(work), need, _stream()),
-            "plsr_item_beh")
+            _ptr(d_U), items, k, _ptr(refd), _ptr(S1), _ptr(S2), _ptr(vst), ld, int(tiled), _ptr(work), need,
+            _stream()), "plsr_item_beh")
         return vst
 
     def rows_project(self, R, rowsq, U, ref=None, S1=None, S2=None):
@@ -806,7 +862,8 @@ class ProjectionEngine:
         return out
 
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
-                   on_batch=None, project_on=None, beh=None, after_enqueue=None, need_nsq=True, cells_fn=None):
+                   on_batch=None, project_on=None, beh=None, after_enqueue=None, need_nsq=True, cells_fn=None,
+                   latent_index=None):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -830,15 +887,24 @@ class ProjectionEngine:
         need_nsq=False: the caller does not use the column norms (behaviour PLS: its per-cell
             z-score of the latent scores is scale invariant); the latent kernel then skips them
             and nsq comes back as NaN.
+        latent_index (R, m) int: the rows of X[:n] whose latent scores the caller reads per resample (its
+            sample, `X_new @ V_hat`): Zt / on_batch's scores are then (.., k, m), column i = row
+            latent_index[b, i] (computed once per DIFFERENT row of the sample, latent_batch_index).
         Returns dict(S1, S2 (p x k shifted moment sums), Zt (R, k, n) = (X VS_b)^T,
         nsq (R, k) = column norms^2 of VS_b)."""
+        index_is_src = latent_index is src
         src = np.ascontiguousarray(src, dtype=np.int32)
         R, nz = src.shape
         n = self.n if latent_rows is None else int(latent_rows)
         refd = self.dev(ref)
         S12 = torch.zeros((2, self.p, k), dtype=torch.float64, device=self.device)
         S1, S2 = S12[0], S12[1]
-        Zt = torch.empty((R, k, n), dtype=torch.float64, device=self.device)
+        if latent_index is not None:
+            latent_index = src if index_is_src else np.ascontiguousarray(latent_index, dtype=np.int32)
+            if latent_index.shape[0] != R or latent_index.ndim != 2:
+                raise ValueError("latent_index must hold one row per resample")
+        Zt = torch.empty((R, k, n if latent_index is None else latent_index.shape[1]), dtype=torch.float64,
+                         device=self.device)
         nsq = torch.empty((R, k), dtype=torch.float64, device=self.device)
         if not need_nsq:
             nsq.fill_(float("nan"))
@@ -925,9 +991,16 @@ class ProjectionEngine:
                 ops = None                       # (the two-stage kernel serves: no dense operator rows)
             else:
                 ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
+            most = tiled = None
+            if latent_index is not None:
+                most = self.distinct_rows(latent_index[lo:hi]) if n <= 128 else 0
             if beh is not None and raw_rows_fn is None:
-                # behaviour PLS: the two-stage kernel takes the z-scored behaviour rows and U themselves
-                vst = self.item_beh(d_src, cell_lo, ranges, beh[0](lo, hi), beh[1], ref=refd, S1=S1, S2=S2, pool=True)
+                # behaviour PLS: the two-stage kernel takes the z-scored behaviour rows and U themselves; its VS^T
+                # leaves tile-major when the latent kernel that streams that layout follows
+                tiled = latent_index is not None and self.index_served(n, k, cnt, latent_index.shape[1], most)
+                vst = self.item_beh(d_src, cell_lo, ranges, beh[0](lo, hi), beh[1], ref=refd, S1=S1, S2=S2, pool=True,
+                                    tiled=tiled)
+                tiled = tiled and vst is not None
                 use_agg = use_agg or vst is not None        # (column norms from the latent kernel)
             if vst is None:
                 vst, rsq = self.item_fused(d_src, cell_lo, cell_z, ops, ref=refd, S1=S1, S2=S2, want_vst=True,
@@ -935,7 +1008,12 @@ class ProjectionEngine:
                                            src_ranges=ranges if use_agg else None, pool=True)
             if not use_agg:
                 nsq[lo:hi] = rsq
-            self.latent_batch(vst, n, Zt[lo:hi], nsq[lo:hi] if use_agg and need_nsq else None)
+            if latent_index is not None:
+                d_li = d_src if index_is_src else self.dev(latent_index[lo:hi], torch.int32)
+                self.latent_batch_index(vst, n, latent_index[lo:hi], d_li, Zt[lo:hi],
+                                        nsq[lo:hi] if use_agg and need_nsq else None, tiled=bool(tiled), most=most)
+            else:
+                self.latent_batch(vst, n, Zt[lo:hi], nsq[lo:hi] if use_agg and need_nsq else None)
             if on_batch is not None:
                 ev = torch.cuda.Event()
                 ev.record()

@@ -191,6 +191,12 @@ def test_two_stage_behaviour_items_random_shapes():
         np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-9, atol=1e-9 * (scale + 1), err_msg=tag)
         np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-9, atol=1e-9 * (scale + 1) ** 2,
                                    err_msg=tag)
+        # the same VS^T tile-major (K5i's operand layout): [item][tile of 32 voxels][k][32], bit for bit
+        tl = eng.item_beh(src, cell_lo, (src_lo, src_hi), Yz, U, tiled=True).cpu().numpy()
+        ppad = (p + 31) // 32 * 32
+        assert tl.shape == (items, k, ppad), tag
+        back = tl.reshape(items, ppad // 32, k, 32).transpose(0, 2, 1, 3).reshape(items, k, ppad)[:, :, :p]
+        np.testing.assert_array_equal(back, vst.cpu().numpy(), err_msg=tag)
     # a row outside its cell's range poisons its item
     src[0, 0] = (src_hi[0] + 1) % n if ncell > 1 else src[0, 0]
     if ncell > 1 and not (src_lo[0] <= src[0, 0] < src_hi[0]):
@@ -467,3 +473,79 @@ def test_rows_project_matches_numpy(shape):
     d = np.transpose(want, (0, 2, 1)) - ref
     np.testing.assert_allclose(S1.cpu().numpy(), d.sum(0), rtol=1e-10, atol=1e-11 * scale * items)
     np.testing.assert_allclose(S2.cpu().numpy(), (d ** 2).sum(0), rtol=1e-10, atol=1e-11 * scale ** 2 * items)
+
+
+@pytest.mark.parametrize("shape", [
+    # n, k, p, items, m, kind of index rows
+    (120, 48, 3001, 9, 120, "boot"), (120, 32, 2050, 5, 200, "boot2"), (128, 16, 515, 4, 128, "perm"),
+    (60, 12, 777, 6, 60, "boot"), (33, 5, 100, 3, 50, "boot"), (97, 64, 1030, 3, 97, "few"),
+    (120, 38, 2050, 5, 200, "boot2"), (120, 48, 200_003, 3, 120, "boot"), (128, 64, 700, 3, 128, "perm"),
+    (140, 16, 300, 2, 140, "boot-full"),
+])
+def test_latent_by_index_matches_numpy(shape):
+    """K5i (plsr_latent_index): L_b = (X[idx_b] VS_b^T)^T computed on the different rows of each sample
+    only, against NumPy: bootstrap samples (about 0.63 n different rows, the count differs from item to item),
+    two samples side by side (m > n), a permutation (every row, n = 128: eight row tiles), a sample of three rows, a
+    long X (voxel ranges of many tiles), more row tiles x tiles of latent variables than a wave holds (k = 38 with
+    seven row tiles, k = 64 with eight: the second launch); with and without the column norms.  "boot-full": more than
+    128 rows -- the engine then takes the full product and gathers its columns."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    n, k, p, items, m, kind = shape
+    rs = np.random.RandomState(n + k + p)
+    X = rs.randn(n, p)
+    eng = ProjectionEngine(X)
+    vs = rs.randn(items, k, p)
+    if kind == "perm":
+        idx = np.stack([rs.permutation(n)[:m] for _ in range(items)])
+    elif kind == "few":
+        idx = rs.choice(rs.choice(n, 3, replace=False), size=(items, m))
+    else:
+        idx = rs.randint(0, n, size=(items, m))
+    idx = idx.astype(np.int32)
+    d_vs, d_idx = eng.dev(vs), eng.dev(idx, torch.int32)
+    want = np.einsum("bjv,biv->bji", vs, X[idx])
+    ppad = (p + 31) // 32 * 32
+    vt = np.full((items, k, ppad), np.nan)                     # (the padding of the last tile is never read as data)
+    vt[:, :, :p] = vs
+    d_vt = eng.dev(np.ascontiguousarray(vt.reshape(items, k, ppad // 32, 32).transpose(0, 2, 1, 3)).reshape(items, k, ppad))
+    for with_norms in (False, True):
+        for tiled in ((False,) if kind.endswith("full") else (False, True)):
+            L = torch.full((items, k, m), float("nan"), dtype=torch.float64, device=eng.device)
+            nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device) if with_norms else None
+            eng.latent_batch_index(d_vt if tiled else d_vs, n, idx, d_idx, L, nsq, tiled=tiled)
+            assert eng.last_latent_kernel == ("full" if kind.endswith("full") else "index")
+            np.testing.assert_allclose(L.cpu().numpy(), want, rtol=1e-11, atol=1e-11 * np.abs(want).max())
+            if with_norms:
+                np.testing.assert_allclose(nsq.cpu().numpy(), (vs ** 2).sum(-1), rtol=1e-12)
+
+
+def test_latent_by_index_refuses_per_item():
+    """An item with more different rows than the caller's bound, or with a row outside X, comes back as NaN; the
+    other items of the launch are served."""
+    import ctypes
+    import torch
+    from plspy_amd import _lib
+    from plspy_amd.engine import ProjectionEngine, _ptr, _stream
+    n, k, p, items, m = 64, 8, 333, 4, 64
+    rs = np.random.RandomState(3)
+    X = rs.randn(n, p)
+    eng = ProjectionEngine(X)
+    vs = rs.randn(items, k, p)
+    idx = np.tile(np.arange(m, dtype=np.int32) % 40, (items, 1))         # 40 different rows
+    idx[1] = np.arange(m)                                                # 64 different rows: over the bound
+    idx[2, 5] = n                                                        # outside X
+    d_vs, d_idx = eng.dev(vs), eng.dev(idx, torch.int32)
+    L = torch.zeros((items, k, m), dtype=torch.float64, device=eng.device)
+    lib = eng.lib
+    need = lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, 48)
+    assert need > 0
+    work = torch.empty(need // 8, dtype=torch.float64, device=eng.device)
+    _lib.check(lib.plsr_latent_index(_ptr(eng._xb(n)), p, n, _ptr(d_vs), d_vs.stride(1), 0, items, k,
+                                     _ptr(d_idx), m, 48, _ptr(L), None, _ptr(work), need, _stream()), "plsr_latent_index")
+    got = L.cpu().numpy()
+    assert np.isnan(got[1]).all() and np.isnan(got[2]).all()
+    for b in (0, 3):
+        np.testing.assert_allclose(got[b], vs[b] @ X[idx[b]].T, rtol=1e-11, atol=1e-11)
+    assert lib.plsr_latent_index_workspace_bytes(129, k, items, p, m, 48) == 0
+    assert lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, n + 1) == 0
