@@ -442,12 +442,20 @@ __global__ __launch_bounds__(BH_WAVES * 64, 2) void item_beh_kernel(BehArgs A) {
                 // index, a chain of three selects per register half where one does)
                 double lo_ = acc2[ii][mc][h], hi_ = acc2[ii][mc][2 + h];
                 asm volatile("" : "+v"(lo_), "+v"(hi_));
+#if defined(PLSR_ABLATE) && (PLSR_ABLATE & 262144)
+                const d2 pc = (d2){lo_, hi_};                           // timing only: no exchange
+#else
                 const double got = swap_pair_f64(odd ? lo_ : hi_);
                 const d2 pc = odd ? (d2){got, hi_} : (d2){lo_, got};
+#endif
                 const int jrow = 16 * mc + 4 * h;
                 char *dst = (char *)base + jrow * rstride + loff;
                 if (whole) {
+#if defined(PLSR_ABLATE) && (PLSR_ABLATE & 524288)
+                  *(d2 *)dst = pc;
+#else
                   __builtin_nontemporal_store(pc, (d2 *)dst);          // streamed: K5 reads it back from HBM anyway
+#endif
                 } else if (jl + jrow < A.k) {
                   if (vcode == 2) {
                     __builtin_nontemporal_store(pc, (d2 *)dst);

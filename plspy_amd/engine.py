@@ -419,7 +419,12 @@ class ProjectionEngine:
     def scale_cols(self, M, scale):
         """M (rows x cols, host or device) times scale per column, on the device: the observed V s
         from V and s.  A host array's device copy is scaled in place; a device tensor is left alone."""
-        Md = self.dev(M).contiguous()
+        if isinstance(M, np.ndarray) and M.ndim == 2 and not M.flags["C_CONTIGUOUS"] and M.T.flags["C_CONTIGUOUS"]:
+            # V as the PLS classes return it: the transpose of the (k, p) block the device produced.  Its bytes go up as
+            # they lie and the layout copy is made on the device (a strided host copy of 77 MB took 20 ms at config 3)
+            Md = self.dev(M.T).t().contiguous()
+        else:
+            Md = self.dev(M).contiguous()
         out = Md if isinstance(M, np.ndarray) else torch.empty_like(Md)
         sd = self.dev(np.ascontiguousarray(scale, dtype=np.float64) if isinstance(scale, np.ndarray) else scale)
         if Md.dim() != 2 or sd.numel() != Md.shape[1]:
