@@ -270,14 +270,21 @@ int plsr_latent_xt(const double *d_XT, int64_t p, int32_t n, const double *d_vst
  * max_rows: the caller's bound on the number of different rows per item (<= n; it sets the workgroup
  * size, one wave per sixteen); an item that exceeds it, or holds an index outside [0, n), comes back
  * as NaN.  d_nsq as for plsr_latent.  vst_tiled != 0: d_vst is tile-major (see plsr_item_beh).
+ * d_T non-null: t_rows (<= 16) further columns d_L[b][j][m + t] = sum_v VS_b[j][v] T_b[d_t_row[t]][v] with
+ * T_b = rows of the item's own block d_T[b] ([t_item_rows][t_ld], row-major) -- the multiblock bootstrap's
+ * Tdistrib: the cell means of smeanmat(X_new_T) @ V_hat are the sample's raw task rows times V_hat
+ * (bootstrap_permutation.py:652-656; class_functions.py:479-490), and those rows are what plsr_split_rows
+ * left in R_b, so the latent kernel needs the rows of the BEHAVIOUR sample only.  d_L is [items][k][m + t_rows].
  */
 size_t plsr_latent_xb_bytes(int32_t n, int64_t p);
 int plsr_latent_xb_prepare(const double *d_X, int64_t ldx, int64_t p, int32_t n, double *d_XB, void *stream);
 size_t plsr_latent_index_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p, int32_t m,
-                                         int32_t max_rows);
+                                         int32_t max_rows, int32_t t_rows);
 int plsr_latent_index(const double *d_XB, int64_t p, int32_t n, const double *d_vst, int64_t ldv,
                       int32_t vst_tiled, int32_t items, int32_t k, const int32_t *d_idx, int32_t m,
-                      int32_t max_rows, double *d_L, double *d_nsq, void *d_work, size_t work_bytes, void *stream);
+                      int32_t max_rows, const double *d_T, int64_t t_ld, int32_t t_item_rows,
+                      const int32_t *d_t_row, int32_t t_rows, double *d_L, double *d_nsq, void *d_work,
+                      size_t work_bytes, void *stream);
 
 /*
  * ---- K0: a handful of operator rows applied to X ------------------------------
@@ -467,12 +474,13 @@ int plsr_split_rows(const double *d_X, int64_t ldx, int64_t p, int32_t n, const 
  *     VS_b^T[j][v] = sum_r d_U[r][j] / sqrt(d_rowsq[b][r]) * R_b[r][v]        (rows 0 .. k - 1 of item b's block)
  * in place (a row of norm 0 contributes 0) and adds the shifted moment sums of VS_b over the items to d_S1 / d_S2
  * ([p][k], shift d_ref or none), as plsr_item_agg does.  d_R [items][kr][ldv], d_U [kr][k], k <= kr <= 48,
- * kr * ldv * 8 < 4 GiB (the query returns 0 otherwise; assumes ldv = p).
+ * kr * ldv * 8 < 4 GiB (the query returns 0 otherwise; assumes ldv = p).  d_out non-null: VS_b^T goes to
+ * d_out [items][k][ldv] instead and R_b stays (plsr_latent_index reads the raw task rows from it).
  */
 size_t plsr_rows_project_workspace_bytes(int32_t kr, int32_t k, int32_t items, int64_t p, int32_t want_moments);
 int plsr_rows_project(double *d_R, int64_t ldv, int64_t p, int32_t items, int32_t kr, const double *d_rowsq,
                       int64_t rowsq_stride, const double *d_U, int32_t k, const double *d_ref, double *d_S1,
-                      double *d_S2, void *d_work, size_t work_bytes, void *stream);
+                      double *d_S2, double *d_out, void *d_work, size_t work_bytes, void *stream);
 
 /*
  * ---- F4: the upstream feed, X built on the device ---------------------------------

@@ -68,7 +68,7 @@ SIGNATURES = {
                                 c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "plsr_rows_project_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64, c_i32]),
     "plsr_rows_project": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                  c_sz, c_vp]),
+                                  c_vp, c_sz, c_vp]),
     "plsr_apply_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "plsr_scale_project_rows": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "plsr_latent_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
@@ -81,11 +81,11 @@ SIGNATURES = {
     "plsr_latent_xt_prepare": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "plsr_latent_xt_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64]),
     "plsr_latent_xt": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "plsr_latent_index_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64, c_i32, c_i32]),
+    "plsr_latent_index_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32]),
     "plsr_latent_xb_bytes": (c_sz, [c_i32, c_i64]),
     "plsr_latent_xb_prepare": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
-    "plsr_latent_index": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp,
-                                  c_vp, c_sz, c_vp]),
+    "plsr_latent_index": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i64,
+                                  c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "plsr_rng_permutation": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "plsr_rng_permutation_seq": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "plsr_rng_task_permutations": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

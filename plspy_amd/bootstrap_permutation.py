@@ -635,7 +635,7 @@ class _ResampleTestPLS(ResampleTest):
                 yz_of[a, z] = cf.zscore_cells(Y[mine[a:z]], bounds)
             return yz_of[a, z]
 
-        def on_batch(a, z, zt, nsq):
+        def on_batch(a, z, zt, nsq, form):
             # LVcorr_b = _compute_corr(X_new @ V_hat, Y_new)   (:638-641); X_new @ V_hat = (X @ V_hat)[inds]
             # (no transposes, and no division by the column norms: see lvcorr_from_latents)
             # -- the engine computes exactly those columns (latent_index: the sample's rows)
@@ -733,8 +733,17 @@ class _ResampleTestPLS(ResampleTest):
         bi_m, ti_m = bi[lo:hi], ti[lo:hi]
         spread, spread_t = self._RunningStd(), self._RunningStd()
 
-        def on_batch(a, z, zt, nsq):
+        def on_batch(a, z, zt, nsq, form):
             Zn = self._normalised_latents(zt, nsq)
+            if form == "index+own":
+                # the engine computed exactly what is read: the scores of the behaviour sample's rows (:647-650) and,
+                # in the last columns, the raw task rows of the sample times V_hat -- the cell means of
+                # smeanmat(X_new_T) @ V_hat (:654-656), the mean-centring being linear
+                LVc[a:z] = cf.corr_rows(Zn[:, :nb], cf.zscore_cells(Yb[bi_m[a:z]], bounds_b), bounds_b)
+                Td[a:z] = Zn[:, nb:]
+                spread.add(LVc[a:z])
+                spread_t.add(Td[a:z])
+                return
             # behaviour latents (:647-650): Xbscan_new @ V_hat = (X @ V_hat)[brows[bi]]
             Lb = np.take_along_axis(Zn, brows[bi_m[a:z]][:, :, None].astype(np.int64), axis=1)
             LVc[a:z] = cf.corr_rows(Lb, cf.zscore_cells(Yb[bi_m[a:z]], bounds_b), bounds_b)
@@ -750,7 +759,7 @@ class _ResampleTestPLS(ResampleTest):
 
         res = eng.boot_items(src, cell_lo, cell_z, k, ops_fn, ref=ref, raw_rows_fn=raw_rows, latent_rows=n,
                              on_batch=on_batch, project_on=U, after_enqueue=self._finalize_early(niter, ref),
-                             cells_fn=cells_fn)
+                             cells_fn=cells_fn, latent_index=brows[bi_m] if cells_ok else None, own_rows=cells_ok)
         std_errs, boot_ratios, (LVcorr, Tdistrib) = self._finish_items(res, [LVc, Td], niter, ref)
         z = norm.ppf(1 - (1 - CI) / 2)
         half = (spread.std() if nranks == 1 else np.std(LVcorr, axis=0)) * z

@@ -294,21 +294,23 @@ __global__ __launch_bounds__(128) void latent_index_meta_kernel(const int32_t *i
   }
 }
 
-// L[item][j][i] = sum over chunks of part[chunk][item][j][cols[item][i]]   (NaN for a refused item)
+// L[item][j][i] = sum over chunks of part[chunk][item][j][cols[item][i]] for i < m, of the columns nr - 16 + (i - m) of
+// the item's own rows for m <= i < m + mt   (NaN for a refused item)
 __global__ __launch_bounds__(256) void latent_index_sum_kernel(const double *part, int64_t items, int k, int nr,
                                                                int nchunk, const int32_t *cols, const int32_t *nu,
-                                                               int m, double *L) {
+                                                               int m, int mt, double *L) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= items * k * m) return;
-  const int i = (int)(e % m);
-  const int64_t bj = e / m;
+  const int mm = m + mt;
+  if (e >= items * k * mm) return;
+  const int i = (int)(e % mm);
+  const int64_t bj = e / mm;
   const int64_t item = bj / k;
   if (nu[item] < 0) {
     L[e] = __builtin_nan("");
     return;
   }
   const int64_t E = items * k * nr;
-  const double *src = part + bj * nr + cols[item * m + i];
+  const double *src = part + bj * nr + (i < m ? cols[item * m + i] : nr - 16 + (i - m));
   double a0 = 0.0, a1 = 0.0;
   int c = 0;
   for (; c + 1 < nchunk; c += 2) {
@@ -524,12 +526,21 @@ struct LatentWaveArgs {
   double *nsq_part;       // [nsplit][items][k] or null
   const int32_t *rows;    // [items][XT_LD]
   const int32_t *nu;      // [items]
-  int32_t nr;             // columns of Zt_part (a multiple of 16)
+  int32_t nr;             // columns of Zt_part (a multiple of 16; with T: the last sixteen are its columns)
   int32_t tile_lo;        // first row tile of this launch (see latent_wave_kernel)
+  // optional extra tile of B rows that are the item's OWN rows (the multiblock's raw task rows): row t of the tile is
+  // row t_row[t] of the item's block of T, row-major; its products land in the last sixteen columns
+  const double *T;        // [items][t_item_rows][t_ld] or null
+  int64_t t_ld;
+  int32_t t_item_rows, t_rows;
+  const int32_t *t_row;   // [t_rows] (device)
 };
 
-template <int MC, int NT>
+// NT tiles of B rows: NT - TT from the item's row list (entries 16 (tile_lo + i) ..), and with TT the tile of the item's
+// own rows last.
+template <int MC, int NT, bool TT>
 __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int item, int split, int lane) {
+  constexpr int NX = NT - (TT ? 1 : 0);
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int col = lane & 15;
   const int g = lane >> 4;
@@ -550,10 +561,11 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
 #pragma unroll
   for (int mc = 0; mc < MC; ++mc) offa[mc] = (uint32_t)(((int64_t)min(mc * 16 + col, A.k - 1) * (A.vst_tiled ? LV_T : A.ldv) + 2 * g) * 8);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
+  for (int i = 0; i < NX; ++i) {
     const int r = min(max(A.rows[(int64_t)item * XT_LD + 16 * (A.tile_lo + i) + col], 0), A.n - 1);
     offb[i] = (uint32_t)((r * LV_T + 2 * g) * 8);
   }
+  if (TT) offb[NT - 1] = (uint32_t)(((int64_t)A.t_row[min(col, A.t_rows - 1)] * A.t_ld + 2 * g) * 8);
   // Both operands through buffer descriptors based at the range's first tile: a load is descriptor + this lane's 32-bit
   // row offset + a scalar tile offset (+ immediate), no 64-bit address arithmetic in registers (with plain pointers
   // the compiler kept a 64-bit address pair per row tile and doubled the B registers: 250 VGPRs and scratch for what
@@ -569,6 +581,10 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
                                                       (int)min(vrange, (int64_t)0x7fffffff), 0x00020000);
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)A.XB + t_lo * xts), 0,
                                                       (int)min(xrange, (int64_t)0x7fffffff), 0x00020000);
+  const char *tbase = TT ? (const char *)(A.T + (int64_t)item * A.t_item_rows * A.t_ld) : nullptr;
+  const int64_t trange = TT ? (int64_t)A.t_item_rows * A.t_ld * 8 - t_lo * (LV_T * 8) : 0;
+  const auto tsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(tbase + (TT ? t_lo * (LV_T * 8) : 0)), 0,
+                                                      (int)min(trange, (int64_t)0x7fffffff), 0x00020000);
   auto load16 = [&](decltype(vsrc) src, uint32_t voff, uint32_t soff) -> d2 {
     const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(src, voff, soff, 0);
     union {
@@ -596,7 +612,7 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) a0[mc] = load16(vsrc, offa[mc], 0);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) b[i] = load16(xsrc, offb[i], 0);
+    for (int i = 0; i < NT; ++i) b[i] = load16(TT && i == NT - 1 ? tsrc : xsrc, offb[i], 0);
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) a1[mc] = load16(vsrc, offa[mc], 64);
     const int nq = 4 * (int)(t_full - t_lo);                     // (even)
@@ -611,7 +627,7 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         mfmas(a, b[i], i);
-        b[i] = load16(xsrc, offb[i], xnext);
+        b[i] = TT && i == NT - 1 ? load16(tsrc, offb[i], (uint32_t)q1 * 64) : load16(xsrc, offb[i], xnext);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -648,9 +664,20 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
         }
       }
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
+      for (int i = 0; i < NX; ++i) {
         const d2 b = *(const d2 *)((const char *)A.XB + t * xts + offb[i] + j * 64);
         mfmas(a, b, i);
+      }
+      if (TT) {
+        const char *rowp = tbase + offb[NT - 1] - 2 * g * 8;
+        d2 b;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int64_t v = t * LV_T + 8 * j + 2 * g + e;
+          const double x = *(const double *)(rowp + min(v, A.p - 1) * 8);
+          b[e] = v < A.p ? x : 0.0;
+        }
+        mfmas(a, b, NT - 1);
       }
     }
   }
@@ -664,7 +691,7 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = mc * 16 + g + 4 * r;
-        if (j < A.k) zo[(int64_t)j * A.nr + 16 * (A.tile_lo + i) + col] = acc[i][mc][r];
+        if (j < A.k) zo[(int64_t)j * A.nr + (TT && i == NT - 1 ? A.nr - 16 : 16 * (A.tile_lo + i)) + col] = acc[i][mc][r];
       }
   if (A.nsq_part) {
 #pragma unroll
@@ -681,7 +708,7 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
 // A wave holds at most latent_wave_cap(MC) row tiles (NT x MC x 8 accumulator registers of the 256 at two waves per
 // SIMD).  Items with more live tiles (a wide sample; k > 48) get the rest from a second launch with tile_lo = cap,
 // whose waves for all other items leave at once.
-constexpr int latent_wave_cap(int mc) { return 18 / mc > 8 ? 8 : 18 / mc; }
+constexpr int latent_wave_cap(int mc) { return mc == 1 ? 8 : mc == 2 ? 7 : 18 / mc; }   // (MC = 2 with eight tiles: 8 bytes of scratch)
 
 template <int MC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void latent_wave_kernel(LatentWaveArgs A) {
@@ -694,18 +721,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int item = (int)(q % A.items);
   const int split = (int)(q / A.items) * 8 + x;
   const int nu = A.nu[item];
-  const int nt = __builtin_amdgcn_readfirstlane(nu < 0 ? 0 : min(((nu + 15) >> 4) - A.tile_lo, CAP));
+  // the item's tiles: its row tiles, then (with T) the tile of its own rows; this launch takes tile_lo .. tile_lo + CAP
+  const int nx = nu < 0 ? -1 : (nu + 15) >> 4;
+  const bool with_t = __builtin_amdgcn_readfirstlane(A.T != nullptr && nx >= A.tile_lo && nx < A.tile_lo + CAP ? 1 : 0) != 0;
+  const int nt = __builtin_amdgcn_readfirstlane(nx < 0 ? 0 : min(nx + (A.T != nullptr ? 1 : 0) - A.tile_lo, CAP));
+#define PLSR_WB(N)                                                    \
+  case N:                                                             \
+    if constexpr (CAP >= N) {                                         \
+      if (with_t)                                                     \
+        latent_wave_body<MC, N, true>(A, item, split, lane);          \
+      else                                                            \
+        latent_wave_body<MC, N, false>(A, item, split, lane);         \
+    }                                                                 \
+    break;
   switch (nt) {
-    case 1: latent_wave_body<MC, 1>(A, item, split, lane); break;
-    case 2: latent_wave_body<MC, 2>(A, item, split, lane); break;
-    case 3: latent_wave_body<MC, 3>(A, item, split, lane); break;
-    case 4: latent_wave_body<MC, 4>(A, item, split, lane); break;
-    case 5: if constexpr (CAP >= 5) latent_wave_body<MC, 5>(A, item, split, lane); break;
-    case 6: if constexpr (CAP >= 6) latent_wave_body<MC, 6>(A, item, split, lane); break;
-    case 7: if constexpr (CAP >= 7) latent_wave_body<MC, 7>(A, item, split, lane); break;
-    case 8: if constexpr (CAP >= 8) latent_wave_body<MC, 8>(A, item, split, lane); break;
+    PLSR_WB(1) PLSR_WB(2) PLSR_WB(3) PLSR_WB(4) PLSR_WB(5) PLSR_WB(6) PLSR_WB(7) PLSR_WB(8)
     default: break;                                  // (nothing for this launch, or a refused item: NaN from the sum kernel)
   }
+#undef PLSR_WB
 }
 
 }  // namespace plsr

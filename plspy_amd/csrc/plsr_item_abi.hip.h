@@ -309,26 +309,31 @@ extern "C" int plsr_latent_xb_prepare(const double *d_X, int64_t ldx, int64_t p,
 }
 
 extern "C" size_t plsr_latent_index_workspace_bytes(int32_t n, int32_t k, int32_t items, int64_t p, int32_t m,
-                                                    int32_t max_rows) {
+                                                    int32_t max_rows, int32_t t_rows) {
   if (n <= 0 || n > XT_LD || k <= 0 || k > 64 || items <= 0 || p <= 0 || m <= 0 || max_rows <= 0 || max_rows > n)
     return 0;                                        // (the row lists hold up to XT_LD = 128 rows of X)
-  if ((int64_t)items * k * m >= ((int64_t)1 << 31)) return 0;
+  if (t_rows < 0 || t_rows > 16) return 0;
+  if ((int64_t)items * k * (m + t_rows) >= ((int64_t)1 << 31)) return 0;
   if ((int64_t)k * ((p + LV_T - 1) / LV_T * LV_T) * 8 >= ((int64_t)1 << 32)) return 0;   // 32-bit offsets into an item's VS^T
   int nsplit, tps;
   index_splits(items, p, nsplit, tps);
-  return index_meta_bytes(items, m) + index_part_bytes(items, k, index_cols(max_rows), nsplit);
+  return index_meta_bytes(items, m) + index_part_bytes(items, k, index_cols(max_rows) + (t_rows ? 16 : 0), nsplit);
 }
 
 extern "C" int plsr_latent_index(const double *d_XB, int64_t p, int32_t n, const double *d_vst, int64_t ldv,
                                  int32_t vst_tiled, int32_t items, int32_t k, const int32_t *d_idx, int32_t m,
-                                 int32_t max_rows, double *d_L, double *d_nsq, void *d_work, size_t work_bytes,
-                                 void *stream) {
+                                 int32_t max_rows, const double *d_T, int64_t t_ld, int32_t t_item_rows,
+                                 const int32_t *d_t_row, int32_t t_rows, double *d_L, double *d_nsq, void *d_work,
+                                 size_t work_bytes, void *stream) {
   if (!d_XB || !d_vst || !d_L || !d_work || !d_idx || ldv < p) return PLSR_EINVAL;
   if (vst_tiled && ldv % LV_T != 0) return PLSR_EINVAL;
-  const size_t need = plsr_latent_index_workspace_bytes(n, k, items, p, m, max_rows);
+  if (!d_T) t_rows = 0;
+  if (t_rows && (!d_t_row || t_ld < p || t_item_rows <= 0)) return PLSR_EINVAL;
+  const size_t need = plsr_latent_index_workspace_bytes(n, k, items, p, m, max_rows, t_rows);
   if (!need) return PLSR_EUNSUPPORTED;
   if (need > work_bytes) return PLSR_EWORKSPACE;
   if ((int64_t)k * ldv * 8 >= ((int64_t)1 << 32) || (int64_t)n * LV_T * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;
+  if (t_rows && (int64_t)t_item_rows * t_ld * 8 >= ((int64_t)1 << 32)) return PLSR_EUNSUPPORTED;
   LatentWaveArgs a;
   index_splits(items, p, a.nsplit, a.tiles_per_split);
   if ((int64_t)items * a.nsplit >= ((int64_t)1 << 31)) return PLSR_EUNSUPPORTED;
@@ -347,19 +352,25 @@ extern "C" int plsr_latent_index(const double *d_XB, int64_t p, int32_t n, const
   a.vst = d_vst;
   a.ldv = ldv;
   a.vst_tiled = vst_tiled != 0;
-  a.nr = index_cols(max_rows);
+  a.nr = index_cols(max_rows) + (t_rows ? 16 : 0);
   a.Zt_part = (double *)((char *)d_work + meta);
   a.nsq_part = d_nsq ? a.Zt_part + (size_t)a.nsplit * items * k * a.nr : nullptr;
   a.rows = rows;
   a.nu = nu;
+  a.T = t_rows ? d_T : nullptr;
+  a.t_ld = t_ld;
+  a.t_item_rows = t_item_rows;
+  a.t_rows = t_rows;
+  a.t_row = d_t_row;
   const int MC = (k + 15) / 16;
+  const int tiles = index_cols(max_rows) / 16 + (t_rows ? 1 : 0);
   const unsigned grid = (unsigned)((int64_t)items * a.nsplit);
   int rc = PLSR_EUNSUPPORTED;
 #define PLSR_LW(M)                                                                            \
   if (MC == M) {                                                                              \
     a.tile_lo = 0;                                                                            \
     hipLaunchKernelGGL((latent_wave_kernel<M>), dim3(grid), dim3(64), 0, st, a);              \
-    if (a.nr / 16 > latent_wave_cap(M)) { /* the row tiles past a wave's capacity */          \
+    if (tiles > latent_wave_cap(M)) { /* the tiles past a wave's capacity */                  \
       a.tile_lo = latent_wave_cap(M);                                                         \
       a.nsq_part = nullptr;                                                                   \
       hipLaunchKernelGGL((latent_wave_kernel<M>), dim3(grid), dim3(64), 0, st, a);            \
@@ -371,10 +382,10 @@ extern "C" int plsr_latent_index(const double *d_XB, int64_t p, int32_t n, const
   a.nsq_part = nsq_part;
 #undef PLSR_LW
   if (rc) return rc;
-  const int64_t EL = (int64_t)items * k * m, EN = (int64_t)items * k;
+  const int64_t EL = (int64_t)items * k * (m + t_rows), EN = (int64_t)items * k;
   hipLaunchKernelGGL(latent_index_sum_kernel, dim3((unsigned)((EL + 255) / 256)), dim3(256), 0, st,
                      (const double *)a.Zt_part, (int64_t)items, (int)k, (int)a.nr, (int)a.nsplit,
-                     (const int32_t *)cols, (const int32_t *)nu, (int)m, d_L);
+                     (const int32_t *)cols, (const int32_t *)nu, (int)m, (int)t_rows, d_L);
   if (d_nsq)
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((EN + 255) / 256), 1), dim3(256), 0, st,
                        (const double *)a.nsq_part, d_nsq, EN, a.nsplit, a.nsplit);

@@ -23,7 +23,8 @@
 namespace plsr {
 
 struct RowsProjArgs {
-  double *R;                 // [items][kr][ldv]  in: R_b, out: rows 0 .. k - 1 = VS_b^T
+  double *R;                 // [items][kr][ldv]  in: R_b, out (when `out` is null): rows 0 .. k - 1 = VS_b^T
+  double *out;               // [items][k][ldv] VS_b^T, or null: in place
   int64_t ldv, p;
   int32_t items, kr, k, ks, per;   // ks = ceil(kr / 4) k-steps; per = items per split
   const double *rdinv;       // [items][4 ks]  1 / |row_r|_b (0 for a row of norm 0 and past kr)
@@ -87,6 +88,10 @@ __global__ __launch_bounds__(256, 2) void rows_project_kernel(RowsProjArgs A) {
 
   const int64_t item_bytes = (int64_t)A.kr * A.ldv * 8;
   char *base = (char *)A.R + (int64_t)it_lo * item_bytes;
+  // results: over R_b (its rows of this voxel column were all read before the first MFMA could issue), or to a
+  // block of their own (R_b stays: the latent kernel reads the raw task rows from it)
+  const int64_t out_bytes = A.out ? (int64_t)A.k * A.ldv * 8 : item_bytes;
+  char *obase = A.out ? (char *)A.out + (int64_t)it_lo * out_bytes : base;
   const double *rdp = A.rdinv + (size_t)it_lo * 4 * ks + g;
   double rn[KSMAX], dn[KSMAX];
 #pragma unroll
@@ -115,8 +120,7 @@ __global__ __launch_bounds__(256, 2) void rows_project_kernel(RowsProjArgs A) {
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc) acc[mc] = mfma_f64(uf[(mc * KSMAX + s) * 64], b[s], acc[mc]);
       }
-    // acc[mc][r] = VS_b[row 16 mc + g + 4 r][voxel]: moments, then in place over R_b (every row of this voxel
-    // column was read before the first MFMA could issue)
+    // acc[mc][r] = VS_b[row 16 mc + g + 4 r][voxel]: moments, then the store
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
@@ -124,9 +128,10 @@ __global__ __launch_bounds__(256, 2) void rows_project_kernel(RowsProjArgs A) {
         const double val = acc[mc][r];
         s1[mc][r] += val;
         s2[mc][r] = fma(val, val, s2[mc][r]);
-        if (vok && 16 * mc + g + 4 * r < A.k) *(double *)(base + so[mc][r]) = val;
+        if (vok && 16 * mc + g + 4 * r < A.k) *(double *)(obase + so[mc][r]) = val;
       }
     base = nb;
+    obase += out_bytes;
     rdp = nd;
   }
   if (A.S1 != nullptr && vok) {

@@ -309,7 +309,7 @@ extern "C" size_t plsr_rows_project_workspace_bytes(int32_t kr, int32_t k, int32
 
 extern "C" int plsr_rows_project(double *d_R, int64_t ldv, int64_t p, int32_t items, int32_t kr, const double *d_rowsq,
                                  int64_t rowsq_stride, const double *d_U, int32_t k, const double *d_ref, double *d_S1,
-                                 double *d_S2, void *d_work, size_t work_bytes, void *stream) {
+                                 double *d_S2, double *d_out, void *d_work, size_t work_bytes, void *stream) {
   if (!d_R || !d_rowsq || !d_U || !d_work || ldv < p || rowsq_stride < kr) return PLSR_EINVAL;
   if ((d_S1 == nullptr) != (d_S2 == nullptr)) return PLSR_EINVAL;
   RowsProjPlan pl;
@@ -320,6 +320,7 @@ extern "C" int plsr_rows_project(double *d_R, int64_t ldv, int64_t p, int32_t it
   char *w = (char *)d_work;
   RowsProjArgs a;
   a.R = d_R;
+  a.out = d_out;
   a.ldv = ldv;
   a.p = p;
   a.items = items;

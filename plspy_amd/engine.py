@@ -488,30 +488,41 @@ class ProjectionEngine:
         srt = np.sort(idx, axis=1)
         return int((np.count_nonzero(srt[:, 1:] != srt[:, :-1], axis=1) + 1).max())
 
-    def index_served(self, n, k, cnt, m, most):
+    def index_served(self, n, k, cnt, m, most, t_rows=0):
         """Whether K5i serves a batch of cnt samples of m rows with at most `most` different ones."""
-        return bool(most) and n <= 128 and self.lib.plsr_latent_index_workspace_bytes(n, k, cnt, self.p, m, most) > 0
+        return bool(most) and n <= 128 and \
+            self.lib.plsr_latent_index_workspace_bytes(n, k, cnt, self.p, m, most, t_rows) > 0
 
-    def latent_batch_index(self, vst, n, idx, d_idx, L, nsq=None, tiled=False, most=None):
+    def latent_batch_index(self, vst, n, idx, d_idx, L, nsq=None, tiled=False, most=None, own=None):
         """K5i: L (cnt, k, m) <- (X[idx_b] VS_b^T)^T, the latent scores of every sample's own rows
         (`_compute_X_latents(X_new, V_hat)` before the normalisation), computed on the rows of X the sample
         holds, each once (plsr_latent_index).  idx (cnt, m): host copy of d_idx (int32, rows of X[:n]).
         tiled: vst is tile-major (item_beh(tiled=True); only K5i reads that layout).
-        Shapes the library does not serve (n > 128): the full product and a gather of its columns."""
+        own = (T (cnt, rows, ld) device block, row indices): t further columns L[b, j, m + t] = VS_b[j] . T_b[row_t]
+        (products with rows of the item's own block -- the multiblock's raw task rows; L is (cnt, k, m + t)).
+        Shapes the library does not serve (n > 128): the full product and a gather of its columns; `own` is then
+        refused (the caller asks index_served first)."""
         cnt, k = int(vst.shape[0]), int(vst.shape[1])
         m = int(idx.shape[1])
+        t_rows = 0 if own is None else len(own[1])
         if most is None:
             most = self.distinct_rows(idx) if n <= 128 else 0
-        if self.index_served(n, k, cnt, m, most):
-            need = self.lib.plsr_latent_index_workspace_bytes(n, k, cnt, self.p, m, most)
+        if self.index_served(n, k, cnt, m, most, t_rows):
+            need = self.lib.plsr_latent_index_workspace_bytes(n, k, cnt, self.p, m, most, t_rows)
             work = self._buf("k5work", need)
+            T = d_tr = None
+            if own is not None:
+                T = own[0]
+                d_tr = self.dev(np.asarray(own[1], dtype=np.int32), torch.int32)
             _lib.check(self.lib.plsr_latent_index(_ptr(self._xb(n)), self.p, n, _ptr(vst), vst.stride(1), int(tiled),
-                                                  cnt, k, _ptr(d_idx), m, most, _ptr(L), _ptr(nsq), _ptr(work),
-                                                  need, _stream()), "plsr_latent_index")
+                                                  cnt, k, _ptr(d_idx), m, most, _ptr(T),
+                                                  0 if T is None else T.stride(1), 0 if T is None else int(T.shape[1]),
+                                                  _ptr(d_tr), t_rows, _ptr(L), _ptr(nsq), _ptr(work), need, _stream()),
+                       "plsr_latent_index")
             self.last_latent_kernel = "index"
             return
-        if tiled:
-            raise _lib.PlsrError("tile-major VS^T is only read by plsr_latent_index")
+        if tiled or own is not None:
+            raise _lib.PlsrError("tile-major VS^T / own-row products are only served by plsr_latent_index")
         Zt = torch.empty((cnt, k, n), dtype=torch.float64, device=self.device)
         self.latent_batch(vst, n, Zt, nsq)
         torch.gather(Zt, 2, d_idx.long()[:, None, :].expand(cnt, k, m), out=L)
@@ -796,11 +807,11 @@ class ProjectionEngine:
             _stream()), "plsr_item_fused")
         return vst, (rowsq[:, :k] if want_rowsq else None)
 
-    def _vst(self, items, k, pool, ld=None):
+    def _vst(self, items, k, pool, ld=None, key="vst"):
         ld = self.p if ld is None else ld
         if not pool:
             return torch.empty((items, k, ld), dtype=torch.float64, device=self.device)
-        return self._buf("vst", items * k * ld * 8)[:items * k * ld * 8].view(torch.float64).view(items, k, ld)
+        return self._buf(key, items * k * ld * 8)[:items * k * ld * 8].view(torch.float64).view(items, k, ld)
 
     def item_beh(self, src, cell_lo, ranges, Yz, U, ref=None, S1=None, S2=None, want_vst=True, pool=False, tiled=False):
         """K4b: VS_b of behaviour PLS in two stages (plsr_item_beh), or None when the shape is not
@@ -831,11 +842,11 @@ class ProjectionEngine:
             _stream()), "plsr_item_beh")
         return vst
 
-    def rows_project(self, R, rowsq, U, ref=None, S1=None, S2=None):
+    def rows_project(self, R, rowsq, U, ref=None, S1=None, S2=None, out=None):
         """K4m (plsr_rows_project): R (items, kr, p) -- the products of the UN-NORMALISED multiblock rows, from
-        item_fused(want_vst=True, want_rowsq=True) with those rows as operator -- becomes VS^T in place,
-        VS_b = (U^T D_b^-1) R_b with D_b = sqrt(rowsq_b); the shifted moment sums are added to S1 / S2.  Returns
-        False (and does nothing) when the shape is not served."""
+        item_fused(want_vst=True, want_rowsq=True) with those rows as operator -- becomes VS^T in place (or goes to
+        `out` (items, k, p), R left as it is), VS_b = (U^T D_b^-1) R_b with D_b = sqrt(rowsq_b); the shifted moment
+        sums are added to S1 / S2.  Returns False (and does nothing) when the shape is not served."""
         items, kr, p = R.shape
         d_U = self.dev(U)
         k = int(d_U.shape[1])
@@ -844,8 +855,8 @@ class ProjectionEngine:
             return False
         work = self._buf("k4mwork", need)
         _lib.check(self.lib.plsr_rows_project(_ptr(R), R.stride(1), p, items, kr, _ptr(rowsq), rowsq.stride(0), _ptr(d_U),
-                                              k, _ptr(self.dev(ref)), _ptr(S1), _ptr(S2), _ptr(work), need, _stream()),
-                   "plsr_rows_project")
+                                              k, _ptr(self.dev(ref)), _ptr(S1), _ptr(S2), _ptr(out), _ptr(work), need,
+                                              _stream()), "plsr_rows_project")
         return True
 
     @staticmethod
@@ -868,7 +879,7 @@ class ProjectionEngine:
 
     def boot_items(self, src, cell_lo, cell_z, k, ops_fn, ref=None, raw_rows_fn=None, latent_rows=None,
                    on_batch=None, project_on=None, beh=None, after_enqueue=None, need_nsq=True, cells_fn=None,
-                   latent_index=None):
+                   latent_index=None, own_rows=False):
         """Bootstrap phase in which every resample has its own gathered /
         z-scored matrix (behaviour and multiblock PLS).
 
@@ -881,10 +892,12 @@ class ProjectionEngine:
             formed on the device, ops_b = U^T diag(1 / rownorm_b) raw_b, and ops_fn
             is not called -- the host never waits for the norms;
         latent_rows: number of leading rows of X used for X @ VS_b (default n).
-        on_batch(lo, hi, Zt_host, nsq_host): optional consumer of every batch's
-            latent scores (NumPy, (hi-lo, k, n) and (hi-lo, k)); it is called one
+        on_batch(lo, hi, Zt_host, nsq_host, form): optional consumer of every batch's
+            latent scores (NumPy, (hi-lo, k, width) and (hi-lo, k)); it is called one
             batch late, while the device already works on the next batch, so the
-            host's per-resample post-processing hides behind the kernels.
+            host's per-resample post-processing hides behind the kernels.  form: "rows" -- width n, column i =
+            row i of X; "index" -- width m, column i = row latent_index[b, i]; "index+own" -- width m + t, the
+            last t columns the products of VS_b with the item's own raw task rows (own_rows).
         cells_fn(lo, hi) -> (cell description of the batch's items as engine.split_rows takes it, Y): with
             project_on, the un-normalised rows come from the two-stage kernel (plsr_split_rows) and the
             projection from the stream over them (plsr_rows_project); raw_rows_fn / ops_fn are then not
@@ -893,9 +906,13 @@ class ProjectionEngine:
             z-score of the latent scores is scale invariant); the latent kernel then skips them
             and nsq comes back as NaN.
         latent_index (R, m) int: the rows of X[:n] whose latent scores the caller reads per resample (its
-            sample, `X_new @ V_hat`): Zt / on_batch's scores are then (.., k, m), column i = row
+            sample, `X_new @ V_hat`): on_batch's scores are then (.., k, m), column i = row
             latent_index[b, i] (computed once per DIFFERENT row of the sample, latent_batch_index).
-        Returns dict(S1, S2 (p x k shifted moment sums), Zt (R, k, n) = (X VS_b)^T,
+        own_rows: with cells_fn and latent_index -- the caller also wants VS_b times the raw TASK rows of the item
+            (the rows of the cells description with row_cell < 0, in row_sub order): the multiblock's Tdistrib,
+            `cell means of smeanmat(X_new_T) @ V_hat` = raw task rows @ V_hat.  Batches the two-stage path serves
+            come back as "index+own"; the others as "rows" (the caller then forms both from the full scores).
+        Returns dict(S1, S2 (p x k shifted moment sums),
         nsq (R, k) = column norms^2 of VS_b)."""
         index_is_src = latent_index is src
         src = np.ascontiguousarray(src, dtype=np.int32)
@@ -908,8 +925,6 @@ class ProjectionEngine:
             latent_index = src if index_is_src else np.ascontiguousarray(latent_index, dtype=np.int32)
             if latent_index.shape[0] != R or latent_index.ndim != 2:
                 raise ValueError("latent_index must hold one row per resample")
-        Zt = torch.empty((R, k, n if latent_index is None else latent_index.shape[1]), dtype=torch.float64,
-                         device=self.device)
         nsq = torch.empty((R, k), dtype=torch.float64, device=self.device)
         if not need_nsq:
             nsq.fill_(float("nan"))
@@ -919,7 +934,7 @@ class ProjectionEngine:
         pending = []
 
         def deliver(job):
-            blo, bhi, ev = job
+            blo, bhi, ev, Zb, form = job
             if self._d2h is None:
                 self._d2h = _side_stream(self.device, "d2h")
             # into page-locked buffers (torch's caching host allocator recycles them): a copy into
@@ -927,14 +942,14 @@ class ProjectionEngine:
             # i.e. update the GPU's page tables while the next batch's kernels run
             with torch.cuda.stream(self._d2h):            # waits for that batch only, not for the stream's tail
                 self._d2h.wait_event(ev)
-                zt_h = torch.empty(Zt[blo:bhi].shape, dtype=Zt.dtype, pin_memory=True)
+                zt_h = torch.empty(Zb.shape, dtype=Zb.dtype, pin_memory=True)
                 nsq_h = torch.empty(nsq[blo:bhi].shape, dtype=nsq.dtype, pin_memory=True)
-                zt_h.copy_(Zt[blo:bhi], non_blocking=True)
+                zt_h.copy_(Zb, non_blocking=True)
                 nsq_h.copy_(nsq[blo:bhi], non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(self._d2h)
             done.synchronize()
-            on_batch(blo, bhi, zt_h.numpy(), nsq_h.numpy())
+            on_batch(blo, bhi, zt_h.numpy(), nsq_h.numpy(), form)
 
         # the cells of a bootstrap sample read fixed ranges of source rows: aggregated-operator
         # kernel (K4a) when the shape allows; it leaves the column norms to the latent kernel
@@ -945,13 +960,26 @@ class ProjectionEngine:
             use_agg = self._agg_bytes(nz, k, cell_lo, cell_z, ranges, cnt, True, False) > 0
             rownorm = None
             vst = None
+            own = None
+            most = tiled = None
+            if latent_index is not None:
+                most = self.distinct_rows(latent_index[lo:hi]) if n <= 128 else 0
             if cells_fn is not None and project_on is not None and np.shape(project_on)[0] == k == np.shape(project_on)[1] \
                     and self.lib.plsr_rows_project_workspace_bytes(k, k, cnt, self.p, 1) > 0:
                 cells, Ycells = cells_fn(lo, hi)
                 got = self.split_rows(cells, Ycells, pool=True) if cells is not None else None
                 if got is not None:
                     vst, rsq = got
-                    if not self.rows_project(vst, rsq, project_on, ref=refd, S1=S1, S2=S2):
+                    # with own_rows the raw rows stay (the latent kernel reads the task rows among them) and VS^T gets
+                    # a block of its own
+                    trows = [i for _, i in sorted((int(sb), i) for i, (c, sb) in
+                                                  enumerate(zip(cells["row_cell"], cells["row_sub"])) if c < 0)]
+                    if own_rows and latent_index is not None and trows and len(trows) <= 16 and \
+                            self.index_served(n, k, cnt, latent_index.shape[1], most, len(trows)):
+                        own = (vst, trows)
+                        vst = self._vst(cnt, k, True, key="vsout")
+                    if not self.rows_project(own[0] if own else vst, rsq, project_on, ref=refd, S1=S1, S2=S2,
+                                             out=vst if own else None):
                         raise _lib.PlsrError("plsr_rows_project declined a shape its workspace query accepted")
                     self.last_item_kernel = "rows+project"
                     use_agg = True                   # (column norms from the latent kernel)
@@ -996,9 +1024,6 @@ class ProjectionEngine:
                 ops = None                       # (the two-stage kernel serves: no dense operator rows)
             else:
                 ops = np.ascontiguousarray(ops_fn(lo, hi, rownorm), dtype=np.float64)  # (cnt, k, nz)
-            most = tiled = None
-            if latent_index is not None:
-                most = self.distinct_rows(latent_index[lo:hi]) if n <= 128 else 0
             if beh is not None and raw_rows_fn is None:
                 # behaviour PLS: the two-stage kernel takes the z-scored behaviour rows and U themselves; its VS^T
                 # leaves tile-major when the latent kernel that streams that layout follows
@@ -1013,16 +1038,21 @@ class ProjectionEngine:
                                            src_ranges=ranges if use_agg else None, pool=True)
             if not use_agg:
                 nsq[lo:hi] = rsq
-            if latent_index is not None:
+            nsq_b = nsq[lo:hi] if use_agg and need_nsq else None
+            if latent_index is not None and (own is not None or not own_rows):
+                m_ix = latent_index.shape[1]
+                form = "index+own" if own else "index"
+                Zb = torch.empty((cnt, k, m_ix + (len(own[1]) if own else 0)), dtype=torch.float64, device=self.device)
                 d_li = d_src if index_is_src else self.dev(latent_index[lo:hi], torch.int32)
-                self.latent_batch_index(vst, n, latent_index[lo:hi], d_li, Zt[lo:hi],
-                                        nsq[lo:hi] if use_agg and need_nsq else None, tiled=bool(tiled), most=most)
+                self.latent_batch_index(vst, n, latent_index[lo:hi], d_li, Zb, nsq_b, tiled=bool(tiled), most=most, own=own)
             else:
-                self.latent_batch(vst, n, Zt[lo:hi], nsq[lo:hi] if use_agg and need_nsq else None)
+                form = "rows"
+                Zb = torch.empty((cnt, k, n), dtype=torch.float64, device=self.device)
+                self.latent_batch(vst, n, Zb, nsq_b)
             if on_batch is not None:
                 ev = torch.cuda.Event()
                 ev.record()
-                pending.append((lo, hi, ev))
+                pending.append((lo, hi, ev, Zb, form))
                 # Two batches stay enqueued behind the one the device runs: the host consumes batch
                 # i - 2 while batch i - 1 runs and batch i waits.  With one batch of slack a late host
                 # (a slow on_batch) left the device idle for a fraction of a millisecond now and then
@@ -1035,7 +1065,7 @@ class ProjectionEngine:
         after = after_enqueue(S1, S2) if after_enqueue is not None else None
         while pending:
             deliver(pending.pop(0))
-        return {"S1": S1, "S2": S2, "S12": S12, "Zt": Zt, "nsq": nsq, "R": R, "after": after}
+        return {"S1": S1, "S2": S2, "S12": S12, "nsq": nsq, "R": R, "after": after}
 
     def eigh(self, G, off, k, init=None, relative=False):
         """Eigen-decomposition of the k x k diagonal block at `off` of every

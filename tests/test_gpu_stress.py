@@ -464,7 +464,12 @@ def test_rows_project_matches_numpy(shape):
     d_sq[:, :kr] = eng.dev(rowsq)
     S1 = torch.zeros((p, kr), dtype=torch.float64, device=eng.device)
     S2 = torch.zeros_like(S1)
+    # to a block of its own first (R stays), then in place: the same bits
+    d_out = torch.full((items, kr, p), float("nan"), dtype=torch.float64, device=eng.device)
+    assert eng.rows_project(d_R, d_sq, U, out=d_out)
+    np.testing.assert_array_equal(d_R.cpu().numpy(), R)
     assert eng.rows_project(d_R, d_sq, U, ref=ref, S1=S1, S2=S2)
+    np.testing.assert_array_equal(d_out.cpu().numpy(), d_R.cpu().numpy())
     with np.errstate(divide="ignore"):
         inv = np.where(rowsq > 0, 1.0 / np.sqrt(rowsq), 0.0)
     want = np.einsum("rj,br,brv->bjv", U, inv, R)
@@ -538,14 +543,46 @@ def test_latent_by_index_refuses_per_item():
     d_vs, d_idx = eng.dev(vs), eng.dev(idx, torch.int32)
     L = torch.zeros((items, k, m), dtype=torch.float64, device=eng.device)
     lib = eng.lib
-    need = lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, 48)
+    need = lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, 48, 0)
     assert need > 0
     work = torch.empty(need // 8, dtype=torch.float64, device=eng.device)
     _lib.check(lib.plsr_latent_index(_ptr(eng._xb(n)), p, n, _ptr(d_vs), d_vs.stride(1), 0, items, k,
-                                     _ptr(d_idx), m, 48, _ptr(L), None, _ptr(work), need, _stream()), "plsr_latent_index")
+                                     _ptr(d_idx), m, 48, None, 0, 0, None, 0, _ptr(L), None, _ptr(work), need,
+                                     _stream()), "plsr_latent_index")
     got = L.cpu().numpy()
     assert np.isnan(got[1]).all() and np.isnan(got[2]).all()
     for b in (0, 3):
         np.testing.assert_allclose(got[b], vs[b] @ X[idx[b]].T, rtol=1e-11, atol=1e-11)
-    assert lib.plsr_latent_index_workspace_bytes(129, k, items, p, m, 48) == 0
-    assert lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, n + 1) == 0
+    assert lib.plsr_latent_index_workspace_bytes(129, k, items, p, m, 48, 0) == 0
+    assert lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, n + 1, 0) == 0
+    assert lib.plsr_latent_index_workspace_bytes(n, k, items, p, m, 48, 17) == 0
+
+
+@pytest.mark.parametrize("shape", [
+    # n, k, p, items, m, rows of the item's own block, which of them
+    (120, 38, 2051, 5, 80, 38, [0, 1, 2, 19, 20, 21]), (120, 38, 640, 3, 80, 38, [5]), (64, 16, 333, 4, 64, 20, list(range(16))),
+    (120, 48, 1000, 3, 120, 48, [47, 0, 13]), (128, 16, 515, 2, 128, 9, [8, 7, 6, 5]),
+])
+def test_latent_by_index_with_own_rows(shape):
+    """K5i with the extra tile of the item's own rows (the multiblock's raw task rows): the columns past m are
+    VS_b . T_b[row_t]; row tiles + own tile within a wave's capacity, past it (second launch: the own tile alone, or
+    with the last row tiles), a single own row, sixteen of them; the other columns unchanged."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    n, k, p, items, m, trows, pick = shape
+    rs = np.random.RandomState(n + k + p)
+    X = rs.randn(n, p)
+    eng = ProjectionEngine(X)
+    vs = rs.randn(items, k, p)
+    T = rs.randn(items, trows, p)
+    idx = (np.stack([rs.permutation(n)[:m] for _ in range(items)]) if n == 128 else rs.randint(0, n, size=(items, m))).astype(np.int32)
+    d_vs, d_idx, d_T = eng.dev(vs), eng.dev(idx, torch.int32), eng.dev(T)
+    want = np.concatenate((np.einsum("bjv,biv->bji", vs, X[idx]), np.einsum("bjv,btv->bjt", vs, T[:, pick])), axis=2)
+    for with_norms in (False, True):
+        L = torch.full((items, k, m + len(pick)), float("nan"), dtype=torch.float64, device=eng.device)
+        nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device) if with_norms else None
+        eng.latent_batch_index(d_vs, n, idx, d_idx, L, nsq, own=(d_T, pick))
+        assert eng.last_latent_kernel == "index"
+        np.testing.assert_allclose(L.cpu().numpy(), want, rtol=1e-11, atol=1e-11 * np.abs(want).max())
+        if with_norms:
+            np.testing.assert_allclose(nsq.cpu().numpy(), (vs ** 2).sum(-1), rtol=1e-12)

@@ -175,10 +175,11 @@ def test_workspace_queries_refuse_what_the_calls_refuse(lib):
     assert lib.plsr_item_beh_workspace_bytes(40, 40, 8, 16, cells, lo, hi, 2, 8, 200_000, 1) > 0
     assert lib.plsr_item_beh_workspace_bytes(40, 40, 8, 16, cells, lo, hi, 2, 8, 42_000_000, 1) == 0
     # K5i: 32-bit offsets into an item's VS^T; at most 128 rows of X; the caller's bound on different rows <= n
-    assert lib.plsr_latent_index_workspace_bytes(120, 48, 125, 200_000, 120, 96) > 0
-    assert lib.plsr_latent_index_workspace_bytes(120, 48, 4, 11_200_000, 120, 96) == 0
-    assert lib.plsr_latent_index_workspace_bytes(129, 48, 4, 200_000, 120, 96) == 0
-    assert lib.plsr_latent_index_workspace_bytes(120, 48, 4, 200_000, 120, 121) == 0
+    assert lib.plsr_latent_index_workspace_bytes(120, 48, 125, 200_000, 120, 96, 0) > 0
+    assert lib.plsr_latent_index_workspace_bytes(120, 38, 125, 200_000, 80, 64, 6) > 0
+    assert lib.plsr_latent_index_workspace_bytes(120, 48, 4, 11_200_000, 120, 96, 0) == 0
+    assert lib.plsr_latent_index_workspace_bytes(129, 48, 4, 200_000, 120, 96, 0) == 0
+    assert lib.plsr_latent_index_workspace_bytes(120, 48, 4, 200_000, 120, 121, 0) == 0
     assert lib.plsr_latent_xb_bytes(120, 200_000) == 200_000 * 120 * 8 and lib.plsr_latent_xb_bytes(129, 200_000) == 0
     # K2s: 32-bit row offsets into X
     rows = (ctypes.c_int32 * 4)(10, 10, 10, 10)
