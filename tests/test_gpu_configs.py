@@ -153,7 +153,7 @@ def rb_problem():
 
 def test_config3_rb_bootstrap_full_batch_plus_ragged(rb_problem):
     """135 bootstraps = one full batch of 125 items (24 GiB scratch limit) + a ragged one of 10,
-    through item_stats / item_fused2<4,64> / latent_kernel<3,1,1,8>."""
+    through K4b (item_beh_kernel, tile-major VS^T) and K5i (latent_wave_kernel on each sample's different rows)."""
     from plspy_amd.bootstrap_permutation import ResampleTest
     co, X, Y, obs = rb_problem
     U, s, V = obs["U"], obs["s"], obs["V"]
@@ -310,6 +310,7 @@ def test_config6_mb_bootstrap_full_size():
     # round 3: the un-normalised rows from the two-stage kernel (plsr_split_rows), the projection as a stream
     # over them (plsr_rows_project)
     assert eng.last_item_kernel == "rows+project", eng.last_item_kernel
+    assert eng.last_latent_kernel == "index"          # (K5i: the behaviour sample's rows + the raw task rows)
     draws = rt.boot_debug_dict["indices"]
     n = 120
     ti, bi = draws[:, :n], draws[:, n:]
