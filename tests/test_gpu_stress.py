@@ -485,7 +485,7 @@ def test_rows_project_matches_numpy(shape):
     (120, 48, 3001, 9, 120, "boot"), (120, 32, 2050, 5, 200, "boot2"), (128, 16, 515, 4, 128, "perm"),
     (60, 12, 777, 6, 60, "boot"), (33, 5, 100, 3, 50, "boot"), (97, 64, 1030, 3, 97, "few"),
     (120, 38, 2050, 5, 200, "boot2"), (120, 48, 200_003, 3, 120, "boot"), (128, 64, 700, 3, 128, "perm"),
-    (140, 16, 300, 2, 140, "boot-full"),
+    (140, 16, 300, 2, 140, "boot-full"), (16, 4, 20, 1, 16, "boot"), (5, 3, 33, 2, 9, "boot"),
 ])
 def test_latent_by_index_matches_numpy(shape):
     """K5i (plsr_latent_index): L_b = (X[idx_b] VS_b^T)^T computed on the different rows of each sample
