@@ -315,6 +315,66 @@ class _ResampleTestPLS(ResampleTest):
         debug = {"s_list": s_hat, "sum_s": total, "sum_perm": total.copy(), "indices": perms}
         return ratio, step, debug
 
+    def _mb_cell_layout(self):
+        """The multiblock of a resample as cells of gathered rows (engine.split_gram / split_rows): behaviour cells
+        first (group x bscan condition), then the task cells (group x condition), whose sums give the task rows --
+        possible when the mean-centring operator W is constant inside a cell.  Returns the constant part of the
+        cell description, or None."""
+        co = self._cond_order
+        bscan = list(self._bscan)
+        ng, nc = co.shape
+        b = np.asarray(self._Ybscan).shape[1]
+        nbs = len(bscan)
+        per = nc + nbs * b
+        bounds_b, bounds_t = cf.cell_bounds(co[:, bscan]), cf.cell_bounds(co)
+        W = self._W
+        Wcell = W[:, bounds_t[:-1]]
+        if not np.array_equal(W, np.repeat(Wcell, np.diff(bounds_t), axis=1)):
+            return None
+        row_cell, row_sub = [], []
+        for g in range(ng):
+            for r in range(per):
+                row_cell.append(-1 if r < nc else g * nbs + (r - nc) // b)
+                row_sub.append(g * nc + r if r < nc else (r - nc) % b)
+        ncb = len(bounds_b) - 1
+        return dict(cell_rows=[int(x) for x in np.diff(bounds_b)] + [int(x) for x in np.diff(bounds_t)], nbq=ncb,
+                    Wc=np.concatenate((np.zeros((ng * nc, ncb)), Wcell), axis=1), row_cell=row_cell, row_sub=row_sub)
+
+    def _perm_mb_grams(self, U, k, niter, task_perm, beh_perm):
+        """The multiblock permutation from per-resample Grams (K2s, engine.split_gram): with R_r the un-normalised
+        rows of resample r (k x p) and D_r their norms, the statistic sum_v (U^T D_r^-1 R_r)^2 per latent variable is
+        diag(U^T Gn_r U) with Gn_r = D_r^-1 R_r R_r^T D_r^-1 -- one pass over the voxels per resample, rows of X read by
+        index, instead of two dense k x (n + nb) products.  Returns (total variance of the observed block, row
+        norms^2 (niter, k), s_hat^2 (niter, q)) or None when the kernel does not serve the shape."""
+        import torch
+        eng = self._engine
+        layout = self._mb_cell_layout() if self._C is None else None
+        if layout is None:
+            return None
+        n = int(self._cond_order.sum())
+        Yb = np.asarray(self._Ybscan, dtype=float)
+        nb = Yb.shape[0]
+        brows = np.flatnonzero(cf.bscan_mask(self._cond_order, list(self._bscan)))
+
+        def grams(task, beh):
+            cells = dict(layout, normalise=True,
+                         xsrc=np.concatenate((np.broadcast_to(brows, beh.shape), task), axis=1),
+                         ysrc=np.concatenate((beh, np.zeros_like(task)), axis=1))
+            return eng.split_gram(cells, Yb)
+        got = grams(np.arange(n, dtype=np.int32)[None], np.arange(nb, dtype=np.int32)[None])
+        if got is None:
+            return None
+        total_s = float((got[1][0, :k] ** 2).sum().item())
+        rank, nranks = dist.world()
+        lo, hi = dist.shard_bounds(niter, rank, nranks)
+        G, rown = grams(task_perm[lo:hi], beh_perm[lo:hi]) if hi > lo else \
+            (torch.zeros((0, k, k), dtype=torch.float64, device=eng.device),) * 2
+        Ut = eng.dev(np.ascontiguousarray(U.T, dtype=np.float64))                 # (q, k)
+        ssq = ((Ut @ G[:, :k, :k]) * Ut).sum(-1).clamp_(min=0.0) if hi > lo else G.new_zeros((0, U.shape[1]))
+        rn2 = rown[:, :k] ** 2 if hi > lo else G.new_zeros((0, k))
+        (ssq, rn2), _ = dist.exchange([ssq.contiguous(), rn2.contiguous()], [], niter)
+        return total_s, rn2.cpu().numpy(), ssq.cpu().numpy()
+
     def _perm_mb(self, U, s, niter, threshold=1e-12):
         """:266-464 for mb.  The multiblock rows are linear in the stacked matrix
         [X; z-scored bscan rows of X]; the per-row normalisation over all voxels
@@ -336,6 +396,18 @@ class _ResampleTestPLS(ResampleTest):
         s[np.abs(s) < threshold] = 0
         mask = cf.bscan_mask(co, bscan)
         bounds_b = cf.cell_bounds(co[:, bscan])
+        draws = self._draw_on_rank0(lambda: self._draw_behaviour_perms(Yb, niter, True))
+        task_perm, beh_perm = draws[:, :n], draws[:, n:]
+        fast = self._perm_mb_grams(U, k, niter, task_perm, beh_perm)
+        if fast is not None:
+            total_s, rownorm2, ssq = fast
+            org_s = np.sqrt(s ** 2 / np.sum(s ** 2) * total_s)
+            total_hat = rownorm2.sum(axis=1)                                         # :419
+            s_hat = np.sqrt(ssq)
+            per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)          # quirk Q3 (:421-423)
+            s_hat = np.sqrt(per_hat * total_hat[:, None])                             # :424
+            ratio, step = self._ratios(s_hat, org_s, org_s, niter)
+            return ratio, step, {"s_list": s_hat, "indices": draws, "org_s": org_s}
         Xzb = eng.gather_zscore(np.flatnonzero(mask), bounds_b, np.ones(len(bounds_b) - 1))[0]
         eng_c = ProjectionEngine(torch.cat((eng.X, Xzb), dim=0), device=eng.device,
                                  work_limit=eng.work_limit)
@@ -358,8 +430,6 @@ class _ResampleTestPLS(ResampleTest):
         total_s = self._run_perm(eng_c, k, 1, cols=A0)[0].sum()
         org_s = np.sqrt(s ** 2 / np.sum(s ** 2) * total_s)
 
-        draws = self._draw_on_rank0(lambda: self._draw_behaviour_perms(Yb, niter, True))
-        task_perm, beh_perm = draws[:, :n], draws[:, n:]
         # task rows of resample r: W P_r  (column i collects W's columns r with perm[r] == i)
         task_rows = np.zeros((niter, ng * nc, n))
         ridx = np.arange(niter)[:, None]
@@ -708,24 +778,15 @@ class _ResampleTestPLS(ResampleTest):
         # the same items as cells of gathered rows (engine.split_rows): behaviour cells first (group x bscan
         # condition: rows brows[bi] of X with rows bi of Ybscan), then the task cells (group x condition: rows ti),
         # whose sums give the task rows -- the mean-centring operator is constant inside a cell
-        bounds_t = cf.cell_bounds(co)
-        Wcell = W[:, bounds_t[:-1]]
-        cells_ok = self._C is None and np.array_equal(W, np.repeat(Wcell, np.diff(bounds_t), axis=1))
-        row_cell, row_sub = [], []
-        for g in range(ng):
-            for r in range(per):
-                row_cell.append(-1 if r < nc else g * nbs + (r - nc) // b)
-                row_sub.append(g * nc + r if r < nc else (r - nc) % b)
-        ncb = len(bounds_b) - 1
-        Wc = np.concatenate((np.zeros((ng * nc, ncb)), Wcell), axis=1)
+        layout = self._mb_cell_layout() if self._C is None else None
+        cells_ok = layout is not None
 
         def cells_fn(a, z):
             if not cells_ok:
                 return None, None
             tb, bb = ti[lo:hi][a:z], bi[lo:hi][a:z]
-            return dict(xsrc=np.concatenate((brows[bb], tb), axis=1), ysrc=np.concatenate((bb, np.zeros_like(tb)), axis=1),
-                        cell_rows=[int(x) for x in np.diff(bounds_b)] + [int(x) for x in np.diff(bounds_t)], nbq=ncb,
-                        Wc=Wc, row_cell=row_cell, row_sub=row_sub), Yb
+            return dict(layout, xsrc=np.concatenate((brows[bb], tb), axis=1),
+                        ysrc=np.concatenate((bb, np.zeros_like(tb)), axis=1)), Yb
 
         cnt = hi - lo
         LVc = np.empty((cnt, (len(bounds_b) - 1) * b, k))

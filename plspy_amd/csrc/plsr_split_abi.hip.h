@@ -17,8 +17,9 @@ struct SplitInstance {
   bool exact;
 };
 // exact instances first: config 4 (mb, two groups x three conditions, bscan of two: eight behaviour cells, twelve
-// task cells, twelve task rows) and the behaviour PLS of config 3's data (twelve behaviour cells)
-const SplitInstance kSplitInst[] = {{4, 6, 1, 3, true},  {6, 0, 0, 3, true},  {5, 5, 1, 3, false},
+// task cells, twelve task rows), the behaviour PLS of config 3's data (twelve behaviour cells) and the multiblock
+// PERMUTATION of the same data (whole samples: four behaviour and six task cells of twenty rows)
+const SplitInstance kSplitInst[] = {{4, 6, 1, 3, true},  {6, 0, 0, 3, true},  {2, 3, 1, 5, true}, {5, 5, 1, 3, false},
                                     {6, 0, 0, 3, false}, {6, 0, 0, 5, false}, {2, 4, 1, 5, false}};
 // the ROWS variant (plsr_split_rows): exact for config 6 (mb bootstrap: four behaviour cells and six task cells of
 // twenty rows), then the guarded ones
@@ -196,10 +197,11 @@ int split_run(const double *d_X, int64_t ldx, int64_t p, int32_t n, const int32_
     switch (pl.inst) {
       case 0: rc = launch_split<4, 6, 1, 3, true>(a, pl, st); break;
       case 1: rc = launch_split<6, 0, 0, 3, true>(a, pl, st); break;
-      case 2: rc = launch_split<5, 5, 1, 3, false>(a, pl, st); break;
-      case 3: rc = launch_split<6, 0, 0, 3, false>(a, pl, st); break;
-      case 4: rc = launch_split<6, 0, 0, 5, false>(a, pl, st); break;
-      case 5: rc = launch_split<2, 4, 1, 5, false>(a, pl, st); break;
+      case 2: rc = launch_split<2, 3, 1, 5, true>(a, pl, st); break;
+      case 3: rc = launch_split<5, 5, 1, 3, false>(a, pl, st); break;
+      case 4: rc = launch_split<6, 0, 0, 3, false>(a, pl, st); break;
+      case 5: rc = launch_split<6, 0, 0, 5, false>(a, pl, st); break;
+      case 6: rc = launch_split<2, 4, 1, 5, false>(a, pl, st); break;
     }
   } else {
     switch (pl.inst) {

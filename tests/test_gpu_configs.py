@@ -290,6 +290,50 @@ def test_config4_planted_graded_spectrum():
     assert max(ratios) < 1e-3 and min(ratios) > 1e-6, ratios         # graded, and within the planted range
 
 
+def test_config6_mb_permutation_full_size():
+    """Multiblock permutation at config 4's data through the per-resample Grams (K2s, exact instance <2,3,1,5>):
+    s_list of selected permutations against the oracle's direct form at full size (its own multiblock of the permuted
+    task rows / permuted behaviour, `.T @ U`, the Q3 rescaling), the ratios against the counts over those values."""
+    from plspy_amd.bootstrap_permutation import ResampleTest
+    from plspy_amd.engine import ProjectionEngine
+    co = np.array([[20] * 3, [20] * 3])
+    X = np.random.RandomState(0).randn(120, 200_000)
+    Y = np.random.RandomState(1).randn(120, 8)
+    bscan = [1, 2]
+    obs = orc.observed("mb", X, co, Y=Y, mctype=0, bscan=bscan)
+    U, s, V = obs["U"], obs["s"], obs["V"]
+    nperm = 37
+    np.random.seed(11)
+    eng = ProjectionEngine(X)
+    calls = []
+    orig = eng.split_gram
+    eng.split_gram = lambda cells, Yb: calls.append(len(cells["xsrc"])) or orig(cells, Yb)
+    rt = ResampleTest._create("mb", X, Y, U, s.copy(), V, co, 0, nperm=nperm, nboot=0, bscan=bscan,
+                              Xbscan=obs["Xbscan"], Ybscan=obs["Ybscan"], lvcorrs_orig=obs["lvcorrs"],
+                              Tvsc_orig=obs["Tvsc_orig"], engine=eng)
+    assert calls == [1, nperm]                        # (the observed block's total variance, then the permutations)
+    draws = rt.perm_debug_dict["indices"]
+    s_list = rt.perm_debug_dict["s_list"]
+    assert s_list.shape == (nperm, 38) and np.isfinite(s_list).all()
+    n = 120
+    live = s > 1e-8 * s[0]
+    for r in (0, 17, nperm - 1):
+        ti, bi = draws[r, :n], draws[r, n:]
+        Xt, Yn = X[ti], obs["Ybscan"][bi]
+        M = orc.create_multiblock(Xt, co, "mb", bscan, 0, Xbscan=obs["Xbscan"], Ybscan=Yn)          # :392
+        s_hat = np.sqrt(np.sum((M.T @ U) ** 2, axis=0))                                               # :404-405
+        raw = orc.create_multiblock(Xt, co, "mb", bscan, 0, norm_opt=False, Xbscan=obs["Xbscan"], Ybscan=Yn)
+        want = np.sqrt(s_hat ** 4 / np.sum(s_hat ** 4) * np.sum(raw ** 2))                           # :413-424 (Q3)
+        assert_close(s_list[r][live], want[live], 1e-9, 0, f"mb perm s_hat[{r}]")
+        # the two latent variables that are null in the OBSERVED block are not null in a permuted one (the null
+        # vectors of the row-normalised block are D w, and D changes with the sample): 1e-6 of the largest here, a
+        # quadratic form of the Gram resolves them to eps k s_1^2 / s_j^2
+        assert (want[~live] > 1e-8 * want[0]).all()
+        assert_close(s_list[r][~live], want[~live], 1e-6, 0, f"mb perm s_hat[{r}], observed-null variables")
+    org_s = rt.perm_debug_dict["org_s"]
+    np.testing.assert_array_equal(rt.permute_ratio, (s_list >= org_s).sum(0) / (nperm + 1))
+
+
 def test_config6_mb_bootstrap_full_size():
     """Multiblock bootstrap (not a BASELINE config; SURVEY a12 on config 4's data): rows (K2s ROWS variant),
     projection (K4m) + K5x at n = 120, kr = 38."""
