@@ -348,7 +348,7 @@ class _ResampleTestPLS(ResampleTest):
         norms^2 (niter, k), s_hat^2 (niter, q)) or None when the kernel does not serve the shape."""
         import torch
         eng = self._engine
-        layout = self._mb_cell_layout() if self._C is None else None
+        layout = self._mb_cell_layout()
         if layout is None:
             return None
         n = int(self._cond_order.sum())
@@ -403,10 +403,14 @@ class _ResampleTestPLS(ResampleTest):
             total_s, rownorm2, ssq = fast
             org_s = np.sqrt(s ** 2 / np.sum(s ** 2) * total_s)
             total_hat = rownorm2.sum(axis=1)                                         # :419
-            s_hat = np.sqrt(ssq)
-            per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)          # quirk Q3 (:421-423)
-            s_hat = np.sqrt(per_hat * total_hat[:, None])                             # :424
-            ratio, step = self._ratios(s_hat, org_s, org_s, niter)
+            s_hat = np.sqrt(ssq)                                                      # :404-405 / :431-432
+            if self._C is None:
+                per_hat = s_hat ** 4 / np.sum(s_hat ** 4, axis=1, keepdims=True)      # quirk Q3 (:421-423)
+                s_hat = np.sqrt(per_hat * total_hat[:, None])                         # :424
+                ratio, step = self._ratios(s_hat, org_s, org_s, niter)
+            else:
+                # cmb compares with s itself (:433) but steps down against the rescaled org_s (:312-319)
+                ratio, step = self._ratios(s_hat, s, org_s, niter)
             return ratio, step, {"s_list": s_hat, "indices": draws, "org_s": org_s}
         Xzb = eng.gather_zscore(np.flatnonzero(mask), bounds_b, np.ones(len(bounds_b) - 1))[0]
         eng_c = ProjectionEngine(torch.cat((eng.X, Xzb), dim=0), device=eng.device,
