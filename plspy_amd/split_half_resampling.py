@@ -358,9 +358,10 @@ def _refine(engine, item, sel, v1, v2, rown, passes, second=True):
 
 
 def _decompose(engine, item, contrasts=None, second=True):
-    """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, H) from the Jacobi eigen-decompositions of the
-    Gram blocks G11 / G22, with H = U1^T G12 U2 (second=False: only the first half is decomposed, U2 = I and
-    s2 = 0 -- split_half_test_train asks nothing else of the second half).  Items with a graded spectrum (a
+    """Per item, as NumPy.  Without contrasts: (U1, s1, U2, s2, H, P) from the Jacobi eigen-decompositions of the
+    Gram blocks G11 / G22, with H = U1^T G12 U2 and P = U1^T U2 (second=False: only the first half is decomposed,
+    U2 = None, s2 = 0, H = U1^T G12 and P = U1^T G12 U1 -- split_half_test_train asks nothing else of the second
+    half).  Items with a graded spectrum (a
     structurally live singular
     value below sqrt(REFINE_RATIO) of the largest) get refinement passes (_refine), so that every live
     singular value keeps LAPACK's accuracy; latent variables that are null for any data (_structural_nulls)
@@ -384,28 +385,35 @@ def _decompose(engine, item, contrasts=None, second=True):
         Gall = Gall.cpu().numpy()
         C = np.asarray(contrasts, dtype=float)
         s1 = np.sqrt(np.einsum("kq,skl,lq->sq", C, Gall[:, :k, :k], C))
-        return None, s1, None, None, C.T @ Gall[:, :k, k:] @ C
+        return None, s1, None, None, C.T @ Gall[:, :k, k:] @ C, None
+    # H = U1^T G12 U2 and the product of the bases the callers ask for -- P = U1^T U2 (split_half, :683), or with
+    # second=False P = U1^T G12 U1 (split_half_test_train, :196) -- are formed on the device right behind the Jacobi
+    # kernels (batched 38 x 38 products; on the host they were 25 of a phase's 150 ms at config 4); the host keeps
+    # the refinement test and redoes the products of the few items it refines
     pending = []
     for sel in batches:
         G, rown = _grams(engine, item, sel)
         e1, v1 = engine.eigh(G, 0, k)
-        want = [e1, v1, G[:, :k, k:2 * k].contiguous()] + ([rown] if rown is not None else [])
+        v1t = v1.transpose(1, 2)
+        G12 = G[:, :k, k:2 * k]
         if second:
-            want += list(engine.eigh(G, k, k))
-        pending.append((sel, engine.fetch_async(want), rown is not None))
-    out = [[] for _ in range(5)]
+            e2, v2 = engine.eigh(G, k, k)
+            want = [e1, v1, v1t @ G12 @ v2, v1t @ v2, e2, v2]
+        else:
+            Hd = v1t @ G12
+            want = [e1, v1, Hd, Hd @ v1]
+        pending.append((sel, engine.fetch_async(want + ([rown] if rown is not None else [])), rown is not None))
+    out = [[] for _ in range(6)]
     if pending:
         nn1, nn2 = _structural_nulls(item)           # (host work beside the kernels)
     for sel, fetch, has_rown in pending:
         got = [np.array(a) for a in fetch.get()]
-        e1, v1, G12 = got[:3]
-        rest = got[3:4] if has_rown else []
+        e1, v1, H, P = got[:4]
+        rest = got[-1:] if has_rown else []
         if second:
-            e2, v2 = got[-2:]
-            H = np.transpose(v1, (0, 2, 1)) @ G12 @ v2
+            e2, v2 = got[4:6]
         else:
-            e2, v2 = np.zeros_like(e1), np.broadcast_to(np.eye(k), v1.shape).copy()
-            H = np.transpose(v1, (0, 2, 1)) @ G12
+            e2, v2 = np.zeros_like(e1), None
         tol = np.full((len(sel), 1), 64 * k * eps)
         # graded spectra: the smallest structurally live eigenvalue against the largest
         ratio = e1[:, max(k - nn1 - 1, 0)] / np.maximum(e1[:, 0], np.finfo(float).tiny)
@@ -414,25 +422,36 @@ def _decompose(engine, item, contrasts=None, second=True):
         need = np.flatnonzero(ratio < REFINE_RATIO)
         if need.size:
             deep = ratio[need] < 1e-9
+            eye = np.eye(k)
             for grp, passes in ((need[~deep], 1), (need[deep], 2)):
                 if grp.size:
-                    r = _refine(engine, item, sel[grp], v1[grp], v2[grp], rest[0][grp] if rest else None, passes, second)
-                    e1[grp], v1[grp], e2[grp], v2[grp], H[grp] = r
+                    w2 = v2[grp] if second else np.broadcast_to(eye, (grp.size, k, k)).copy()
+                    r = _refine(engine, item, sel[grp], v1[grp], w2, rest[0][grp] if rest else None, passes, second)
+                    e1[grp], v1[grp], e2[grp], H[grp] = r[0], r[1], r[2], r[4]
+                    if second:
+                        v2[grp] = r[3]
+                        P[grp] = np.transpose(r[1], (0, 2, 1)) @ r[3]
+                    else:
+                        P[grp] = r[4] @ r[1]
             tol[need] = (4 * k * eps) ** 2
         for e, nn in ((e1, nn1), (e2, nn2)):
             e[e <= tol * np.maximum(e[:, :1], 0.0)] = 0.0
             if nn:
                 e[:, k - nn:] = 0.0
-        for acc, a in zip(out, (e1, v1, e2, v2, H)):
+        for acc, a in zip(out, (e1, v1, e2, v2 if second else e2[:, :0], H, P)):
             acc.append(a)
     if pending:
-        e1, v1, e2, v2, H = (np.concatenate(acc) for acc in out)
+        e1, v1, e2, v2, H, P = (np.concatenate(acc) for acc in out)
     else:
-        e1, v1, e2, v2, H = (np.zeros(shape) for shape in ((0, k), (0, k, k), (0, k), (0, k, k), (0, k, k)))
+        e1, v1, e2, v2, H, P = (np.zeros(shape) for shape in ((0, k), (0, k, k), (0, k), (0, k, k) if second else (0, 0),
+                                                           (0, k, k), (0, k, k)))
     if nranks > 1:
-        send, _ = dist.exchange([engine.dev(np.ascontiguousarray(a)) for a in (e1, v1, e2, v2, H)], [], S)
-        e1, v1, e2, v2, H = (t.cpu().numpy() for t in send)
-    return v1, np.sqrt(e1), v2, np.sqrt(e2), H
+        parts = [e1, v1, e2, H, P] + ([v2] if second else [])
+        send, _ = dist.exchange([engine.dev(np.ascontiguousarray(a)) for a in parts], [], S)
+        got = [t.cpu().numpy() for t in send]
+        e1, v1, e2, H, P = got[:5]
+        v2 = got[5] if second else None
+    return v1, np.sqrt(e1), v2 if second else None, np.sqrt(e2), H, P
 
 
 def _inv(s):
@@ -487,11 +506,10 @@ def split_half_test_train(pls_alg, matrix, Y, cond_order, num_split, mctype=None
     d = k if contrasts is None else np.asarray(contrasts).shape[1]             # :79-86
     if matrix.shape[1] < d:
         raise exceptions.NotImplementedError("split-half with fewer voxels than latent variables")
-    U1, s1, U2, _, H = _decompose(engine, item, contrasts, second=False)
+    U1, s1, _, _, H, P = _decompose(engine, item, contrasts, second=False)
     train = np.repeat(s1[:, None, :], d, axis=1)                       # :195 (row broadcast, Q11)
     if contrasts is None:
-        # V1.T M2.T U1 = S1^-1 U1.T G12 U1 = S1^-1 H (U1.T U2).T with H = U1.T G12 U2          (:196)
-        test = _inv(s1)[:, :, None] * (H @ np.transpose(np.transpose(U1, (0, 2, 1)) @ U2, (0, 2, 1)))
+        test = _inv(s1)[:, :, None] * P                                # V1.T M2.T U1 = S1^-1 U1.T G12 U1   (:196)
     else:
         test = H                                                       # V.T @ M2.T @ U = C.T M1 M2.T C (:220)
     S = num_split
@@ -515,10 +533,10 @@ def split_half(pls_alg, matrix, Y, cond_order, num_split, mctype=None, contrasts
                Xbscan=None, Ybscan=None, lv=1, CI=0.95, engine=None):
     """split_half_resampling.py:404-861."""
     engine, item = _prepare(pls_alg, matrix, Y, cond_order, num_split, mctype, bscan, engine)
-    U1, s1, U2, s2, H = _decompose(engine, item, contrasts)
+    U1, s1, U2, s2, H, P = _decompose(engine, item, contrasts)
     if contrasts is None:
         u_rep = (_inv(s1)[:, :, None] * H) * _inv(s2)[:, None, :]       # V1.T V2 = S1^-1 U1.T G12 U2 S2^-1  (:682)
-        v_rep = np.transpose(U1, (0, 2, 1)) @ U2                                                         # :683
+        v_rep = P                                                       # U1.T U2                             (:683)
     else:
         C = np.asarray(contrasts, dtype=float)
         u_rep = H                                                      # V1.T @ V2 = C.T M1 M2.T C  (:682)
