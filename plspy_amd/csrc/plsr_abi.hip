@@ -753,7 +753,7 @@ extern "C" int plsr_eigh_batch(const double *d_G, int64_t item_stride, int32_t l
   if (!d_G || !d_evals || !d_evecs || count <= 0 || k <= 0 || ld < off + k) return PLSR_EINVAL;
   if (k > EIG_MAX) return PLSR_EUNSUPPORTED;
   if (d_init == d_evecs) return PLSR_EINVAL;          // the output is written in sorted column order
-  hipLaunchKernelGGL(eigh_kernel, dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream, d_G,
+  hipLaunchKernelGGL(eigh_kernel, dim3((unsigned)count), dim3(64), eigh_lds_bytes(k), (hipStream_t)stream, d_G,
                      item_stride, ld, off, k, count, d_evals, d_evecs, 30, d_init, (int)(relative != 0));
   return check_launch();
 }

@@ -407,18 +407,24 @@ constexpr int EIG_MAX = 64;
 // graded norms (a refinement pass: G = D A D, A close to I, entry errors ~ eps d_i d_j), where
 // two-sided Jacobi is RELATIVELY accurate (Demmel & Veselic) as long as no rotation is skipped
 // for being small in absolute terms -- the noise clause below is then switched off.
+__host__ __device__ inline int eigh_pitch(int k) { return (k | 1) + ((k & 1) ? 2 : 0); }      // odd, > k
+inline size_t eigh_lds_bytes(int k) { return (size_t)2 * k * eigh_pitch(k) * sizeof(double); }
+
 __global__ __launch_bounds__(64) void eigh_kernel(const double *Gsrc, int64_t item_stride, int ld,
                                                   int off, int k, int count, double *evals,
                                                   double *evecs, int max_sweeps, const double *init,
                                                   int relative) {
-  __shared__ double As[EIG_MAX * (EIG_MAX + 1)];
-  __shared__ double Vs[EIG_MAX * (EIG_MAX + 1)];
+  // A and V in LDS, k rows of an odd pitch each -- sized by k at launch (eigh_lds_bytes): with the pitch of the largest
+  // matrix (64 + 1: 66 KB per workgroup) a CU held two of these one-wave workgroups, and the kernel is bound by the
+  // latency of its LDS round trips (at k = 38: 24 KB, six per CU)
+  extern __shared__ double eig_sm[];
   __shared__ double cs[EIG_MAX], sn[EIG_MAX];
   __shared__ int pp[EIG_MAX], qq[EIG_MAX];
   const int item = blockIdx.x;
   if (item >= count) return;
   const int lane = threadIdx.x;
-  const int LD = EIG_MAX + 1;
+  const int LD = eigh_pitch(k);
+  double *As = eig_sm, *Vs = eig_sm + k * LD;
   const double *G = Gsrc + (int64_t)item * item_stride + (int64_t)off * ld + off;
   const int kk = (k + 1) & ~1;            // players in the tournament (one dummy if k is odd)
   for (int e = lane; e < k * k; e += 64) {
