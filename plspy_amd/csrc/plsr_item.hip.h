@@ -569,7 +569,7 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
   // Both operands through buffer descriptors based at the range's first tile: a load is descriptor + this lane's 32-bit
   // row offset + a scalar tile offset (+ immediate), no 64-bit address arithmetic in registers (with plain pointers
   // the compiler kept a 64-bit address pair per row tile and doubled the B registers: 250 VGPRs and scratch for what
-  // needs 110).
+  // needs 110).  (The record counts are unsigned 32-bit: an item's VS^T may span up to 4 GiB.)
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const char *vbase = (const char *)(A.vst + (int64_t)item * A.k * A.ldv);
   const int64_t xts = (int64_t)A.n * LV_T * 8;                    // bytes per tile of XB
@@ -578,13 +578,13 @@ __device__ __forceinline__ void latent_wave_body(const LatentWaveArgs &A, int it
   const int64_t vrange = (int64_t)A.k * A.ldv * 8 - t_lo * vts;
   const int64_t xrange = (nvt - t_lo) * xts;
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(vbase + t_lo * vts), 0,
-                                                      (int)min(vrange, (int64_t)0x7fffffff), 0x00020000);
+                                                      (int)(uint32_t)min(vrange, (int64_t)0xffffffff), 0x00020000);
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)A.XB + t_lo * xts), 0,
-                                                      (int)min(xrange, (int64_t)0x7fffffff), 0x00020000);
+                                                      (int)(uint32_t)min(xrange, (int64_t)0xffffffff), 0x00020000);
   const char *tbase = TT ? (const char *)(A.T + (int64_t)item * A.t_item_rows * A.t_ld) : nullptr;
   const int64_t trange = TT ? (int64_t)A.t_item_rows * A.t_ld * 8 - t_lo * (LV_T * 8) : 0;
   const auto tsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(tbase + (TT ? t_lo * (LV_T * 8) : 0)), 0,
-                                                      (int)min(trange, (int64_t)0x7fffffff), 0x00020000);
+                                                      (int)(uint32_t)min(trange, (int64_t)0xffffffff), 0x00020000);
   auto load16 = [&](decltype(vsrc) src, uint32_t voff, uint32_t soff) -> d2 {
     const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(src, voff, soff, 0);
     union {

@@ -440,6 +440,32 @@ def test_latent_of_an_x_beyond_4_gib():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("tiled", [False, True])
+def test_latent_by_index_of_a_vs_beyond_2_gib(tiled):
+    """K5i reaches VS^T through buffer descriptors with 32-bit offsets: an item of 64 x 5 000 000 doubles (2.56 GB:
+    past the 2 GiB a signed record count would cover, below the 4 GiB the library accepts), row-major and
+    tile-major, against torch's own fp64 product."""
+    import torch
+    from plspy_amd.engine import ProjectionEngine
+    n, p, k, items, m = 24, 5_000_000, 64, 1, 24
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn((n, p), dtype=torch.float64, device="cuda", generator=g)
+    vs = torch.randn((items, k, p), dtype=torch.float64, device="cuda", generator=g)
+    eng = ProjectionEngine(X)
+    idx = np.random.RandomState(2).randint(0, n, size=(items, m)).astype(np.int32)
+    d_idx = eng.dev(idx, torch.int32)
+    want = torch.matmul(vs, X[torch.as_tensor(idx[0], device="cuda").long()].t())
+    d_vs = vs.view(items, k, p // 32, 32).transpose(1, 2).contiguous().view(items, k, p) if tiled else vs
+    L = torch.empty((items, k, m), dtype=torch.float64, device=eng.device)
+    nsq = torch.empty((items, k), dtype=torch.float64, device=eng.device)
+    eng.latent_batch_index(d_vs, n, idx, d_idx, L, nsq, tiled=tiled)
+    assert eng.last_latent_kernel == "index"
+    assert float((L - want).abs().max()) <= 1e-11 * float(want.abs().max())
+    assert torch.allclose(nsq, (vs * vs).sum(-1), rtol=1e-11)
+    del X, vs, want, d_vs
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("shape", [
     # kr = k, p, items
     (38, 2001, 9), (5, 130, 3), (16, 64, 17), (33, 777, 4), (48, 515, 6), (1, 31, 2),
