@@ -160,6 +160,8 @@ class ProjectionEngine:
         self._tail = None
         self._h2d = None
         self._d2h = None
+        self.last_item_kernel = None          # which VS / latent kernels the last batch took (read by the tests)
+        self.last_latent_kernel = None
 
     # -- helpers -----------------------------------------------------------
     def _buf(self, name, nbytes):
